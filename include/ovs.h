@@ -1,0 +1,415 @@
+/*
+ * ovs.h -- C ABI of the MI355X (gfx950) ORB extraction + binary-descriptor matching library.
+ *
+ * This is the drop-in boundary for the front-end hot path of OpenVSLAM
+ * (feature::orb_extractor::extract() and match::{projection,stereo,robust,bow_tree}).
+ * The reference has no FFI layer for this path: it is ordinary C++ classes
+ * (src/openvslam/feature/orb_extractor.h:13-150, src/openvslam/match/{projection,stereo,robust,bow_tree}.h), so every entry
+ * point below cites the class member it replaces.  A header-only C++ shim that restores the
+ * reference's class names on top of these functions lives in openvslam_amd/cpp/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; nothing here depends on torch, OpenCV or Eigen;
+ *  - every function returns an ovs_status (0 = ok, <0 = error); the message of the last error
+ *    of the calling thread is available from ovs_last_error();
+ *  - "host" entry points take host pointers and copy; "_dev" entry points take device (HBM)
+ *    pointers and enqueue work on the given hipStream_t (passed as void*), without syncing;
+ *  - the library never keeps a caller pointer after the call returns (the reference deep-copies
+ *    descriptors the same way, src/openvslam/data/keyframe.cc:28);
+ *  - an extractor handle is stateful and not re-entrant, exactly like the reference object
+ *    (image_pyramid_, rect_mask_: src/openvslam/feature/orb_extractor.h:75,136-137); distinct
+ *    handles may be used from distinct threads (left/right extraction,
+ *    src/openvslam/data/frame.cc:64-67).  Matcher entry points keep no global state.
+ */
+#ifndef OVS_H
+#define OVS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ovs_status {
+    OVS_OK = 0,
+    OVS_ERR_INVALID_ARGUMENT = -1, /* std::runtime_error / assert in the reference           */
+    OVS_ERR_CAPACITY = -2,         /* caller buffer too small for the result                  */
+    OVS_ERR_HIP = -3,              /* a HIP runtime call failed                               */
+    OVS_ERR_UNSUPPORTED = -4,      /* a configuration the device path does not implement      */
+    OVS_ERR_OUT_OF_RANGE = -5      /* std::out_of_range from .at() in the reference           */
+} ovs_status;
+
+const char* ovs_last_error(void);
+/* Number of visible HIP devices (<=0 if none).  Never falls back to a CPU path. */
+int ovs_device_count(void);
+
+/* Binary layout of cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id.
+ * extract() fills them as src/openvslam/feature/orb_extractor.cc:380-389,594,598-606 do. */
+typedef struct ovs_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} ovs_keypoint;
+
+/* ------------------------------------------------------------------------------------------ */
+/* ORB extractor                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* feature::orb_params (src/openvslam/feature/orb_params.h, orb_params.cc:8-33). */
+typedef struct ovs_orb_params {
+    uint32_t max_num_keypts;
+    float scale_factor;
+    uint32_t num_levels;
+    uint32_t ini_fast_thr;
+    uint32_t min_fast_thr;
+    uint32_t num_mask_rects;
+    const float* mask_rects; /* num_mask_rects x {x_min, x_max, y_min, y_max} as image ratios */
+} ovs_orb_params;
+
+/* Fills the defaults of orb_params(const YAML::Node&): 2000 / 1.2 / 8 / 20 / 7 / no rects
+ * (src/openvslam/feature/orb_params.cc:27-33). */
+void ovs_orb_params_default(ovs_orb_params* p);
+
+/* Static scale tables, orb_params::calc_* (src/openvslam/feature/orb_params.cc:53-87). */
+void ovs_calc_scale_factors(uint32_t num_levels, float scale_factor, float* out);
+void ovs_calc_inv_scale_factors(uint32_t num_levels, float scale_factor, float* out);
+void ovs_calc_level_sigma_sq(uint32_t num_levels, float scale_factor, float* out);
+void ovs_calc_inv_level_sigma_sq(uint32_t num_levels, float scale_factor, float* out);
+
+typedef struct ovs_orb ovs_orb;
+
+/* orb_extractor::orb_extractor(const orb_params&) (orb_extractor.cc:62-66).  Mask-rectangle
+ * validation errors of orb_params.cc:14-24 come back as OVS_ERR_INVALID_ARGUMENT with the
+ * reference's message.  `device` is the HIP device ordinal the handle lives on. */
+int ovs_orb_create(const ovs_orb_params* params, int device, ovs_orb** out);
+void ovs_orb_destroy(ovs_orb* h);
+
+/* Getters / setters of orb_extractor.cc:146-203.  As in the reference, changing keypoints /
+ * scale factor / levels re-runs initialize(); changing thresholds does not. */
+uint32_t ovs_orb_get_max_num_keypoints(const ovs_orb* h);
+int ovs_orb_set_max_num_keypoints(ovs_orb* h, uint32_t v);
+float ovs_orb_get_scale_factor(const ovs_orb* h);
+int ovs_orb_set_scale_factor(ovs_orb* h, float v);
+uint32_t ovs_orb_get_num_scale_levels(const ovs_orb* h);
+int ovs_orb_set_num_scale_levels(ovs_orb* h, uint32_t v);
+uint32_t ovs_orb_get_initial_fast_threshold(const ovs_orb* h);
+int ovs_orb_set_initial_fast_threshold(ovs_orb* h, uint32_t v);
+uint32_t ovs_orb_get_minimum_fast_threshold(const ovs_orb* h);
+int ovs_orb_set_minimum_fast_threshold(ovs_orb* h, uint32_t v);
+int ovs_orb_get_scale_factors(const ovs_orb* h, float* out);
+int ovs_orb_get_inv_scale_factors(const ovs_orb* h, float* out);
+int ovs_orb_get_level_sigma_sq(const ovs_orb* h, float* out);
+int ovs_orb_get_inv_level_sigma_sq(const ovs_orb* h, float* out);
+/* num_keypts_per_level_ of orb_extractor.cc:214-223 (num_levels values). */
+int ovs_orb_get_num_keypts_per_level(const ovs_orb* h, uint32_t* out);
+
+/* Upper bound on the number of keypoints extract() can return for a width x height image.
+ * The quadtree of orb_extractor.cc:398-475 may exceed the per-level quota (a sweep stops once
+ * `quota <= nodes.size()`), so this is larger than max_num_keypts; size output buffers with it. */
+int ovs_orb_keypoint_capacity(const ovs_orb* h, int width, int height);
+
+/* orb_extractor::extract() (orb_extractor.cc:68-144), one frame, host buffers.
+ *   img          CV_8UC1 image, `stride` bytes per row; width==0 or height==0 or img==NULL is
+ *                the reference's "empty image": returns OVS_OK without touching the outputs.
+ *   mask         optional CV_8UC1 image mask of the same size (0 = masked); NULL selects the
+ *                rectangle mask of the params if any, else no mask (orb_extractor.cc:90-104).
+ *   kps, desc    caller buffers of `cap` keypoints / cap x 32 bytes; *n receives the count.
+ * Synchronous. */
+int ovs_orb_extract(ovs_orb* h, const uint8_t* img, int width, int height, size_t stride,
+                    const uint8_t* mask, size_t mask_stride,
+                    ovs_keypoint* kps, uint8_t* desc, int cap, int* n);
+
+/* The same for a batch of equally sized frames already resident in HBM (offline batches).
+ *   d_imgs       n_frames images, row_stride bytes per row, frame_stride bytes per frame
+ *   d_mask       optional level-0 mask shared by all frames (NULL: rectangle mask / none)
+ *   d_kps        n_frames x cap keypoints; d_desc n_frames x cap x 32 bytes; d_counts n_frames
+ *   stream       hipStream_t; work is enqueued, not synchronised.
+ * A frame whose keypoint count exceeds `cap` gets d_counts[f] = -(count) and truncated output. */
+int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, int width, int height,
+                              size_t row_stride, size_t frame_stride,
+                              const uint8_t* d_mask, size_t mask_stride,
+                              ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap,
+                              void* stream);
+
+/* image_pyramid_ (orb_extractor.h:75) of the last extract call, read by match::stereo
+ * (src/openvslam/data/frame.cc:77).  Level 0 is the caller's image and is not retained by the
+ * library; levels >= 1 stay resident on the device until the next extract on this handle. */
+int ovs_orb_pyramid_level_dev(ovs_orb* h, int frame, int level,
+                              const uint8_t** d_ptr, int* width, int* height, size_t* stride);
+/* Host copy of one pyramid level (levels >= 1) into `out` with `out_stride` bytes per row. */
+int ovs_orb_download_pyramid_level(ovs_orb* h, int frame, int level, uint8_t* out, size_t out_stride);
+/* Host copy of the Gaussian-blurred level used for the descriptors (orb_extractor.cc:132-133);
+ * a debugging / parity hook, the reference keeps this image local. */
+int ovs_orb_download_blurred_level(ovs_orb* h, int frame, int level, uint8_t* out, size_t out_stride);
+/* Size of pyramid level `level` for a width x height input (orb_extractor.cc:267-268). */
+int ovs_orb_level_size(const ovs_orb* h, int width, int height, int level, int* w, int* hh);
+
+/* Per-kernel device timing of the extract/match launches of this thread: when enabled every
+ * launch is bracketed by hipEvents on its stream; query returns accumulated milliseconds and the
+ * launch count for a kernel name since the last reset.  Diagnostics only. */
+void ovs_timing_enable(int on);
+void ovs_timing_reset(void);
+int ovs_timing_query(const char* kernel_name, double* total_ms, int* launches);
+/* Writes up to `cap` names (each <= 63 chars + NUL, 64-byte slots) and returns the count. */
+int ovs_timing_names(char* names, int cap);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Descriptor distance                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* match::compute_descriptor_distance_32 (src/openvslam/match/base.h:18-39) for n pairs of
+ * 32-byte descriptors: out[i] = hamming(a[i], b[i]).  Host buffers, computed on the device. */
+int ovs_hamming_pairs(const uint8_t* a, const uint8_t* b, int n, uint32_t* out, int device);
+/* All-pairs distance matrix out[i*nb + j] = hamming(a[i], b[j]) (host buffers). */
+int ovs_hamming_matrix(const uint8_t* a, int na, const uint8_t* b, int nb, uint16_t* out, int device);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Frame views used by the matchers                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Grid geometry of camera::base (src/openvslam/camera/base.h:117-130,
+ * src/openvslam/camera/perspective.cc:27-30): image bounds and inverse cell sizes. */
+typedef struct ovs_grid {
+    float min_x, min_y, max_x, max_y;
+    double inv_cell_width, inv_cell_height;
+    uint32_t num_cols, num_rows; /* 64 x 48 in the reference (camera/base.cc) */
+} ovs_grid;
+
+/* The fields of data::frame / data::keyframe the matchers read, flattened by the caller
+ * (landmark getters take mutexes, src/openvslam/data/landmark.cc:30-33, and stay on the host). */
+typedef struct ovs_frame_view {
+    int32_t num_keypts;
+    const ovs_keypoint* undist_keypts; /* undist_keypts_: pt, octave, angle are read        */
+    const uint8_t* descriptors;        /* num_keypts x 32                                    */
+    const float* stereo_x_right;       /* num_keypts, or NULL meaning all -1 (monocular)     */
+    const float* scale_factors;        /* num_scale_levels                                   */
+    int32_t num_scale_levels;
+    ovs_grid grid;
+} ovs_frame_view;
+
+/* data::get_cell_indices (src/openvslam/data/common.h:59-64): returns 1 if inside the grid. */
+int ovs_get_cell_indices(const ovs_grid* g, float x, float y, int* cell_x, int* cell_y);
+
+/* data::assign_keypoints_to_grid + data::get_keypoints_in_cell
+ * (src/openvslam/data/common.cc:97-186) for n_queries windows against one frame: query q
+ * writes its indices (reference order: cell-x major, cell-y, insertion order) to
+ * out_indices[out_offsets[q] .. out_offsets[q+1]).  out_offsets has n_queries+1 entries.
+ * Host buffers, computed on the device. */
+int ovs_get_keypoints_in_cell(const ovs_frame_view* frm, int n_queries,
+                              const float* ref_xy, const float* margin,
+                              const int32_t* min_level, const int32_t* max_level,
+                              uint32_t* out_indices, int cap, uint32_t* out_offsets, int device);
+
+/* ------------------------------------------------------------------------------------------ */
+/* match::projection                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* One entry per 3-D point projected into the frame being searched.  The projection itself
+ * (camera_->reproject_to_image, double precision, src/openvslam/match/projection.cc:127) is
+ * done by the caller; these are its outputs plus the landmark fields the loop body reads. */
+typedef struct ovs_proj_queries {
+    int32_t n;
+    const float* reproj_xy;         /* n x 2: reproj(0), reproj(1)                             */
+    const float* x_right;           /* n: x_right of the reprojection (NULL: unused)           */
+    const int32_t* scale_level;     /* n: last_frm octave / predicted scale level              */
+    const float* angle;             /* n: undistorted keypoint angle of the source (or NULL)   */
+    const uint8_t* desc;            /* n x 32: lm->get_descriptor()                            */
+    const uint8_t* valid;           /* n: 0 = the reference `continue`s before the search      */
+    const uint8_t* has_observation; /* n: lm->has_observation() (NULL: all 1)                  */
+} ovs_proj_queries;
+
+enum { OVS_DIR_NONE = 0, OVS_DIR_FORWARD = 1, OVS_DIR_BACKWARD = 2 };
+
+/* projection::match_current_and_last_frames (src/openvslam/match/projection.cc:84-209).
+ *   curr_occupied   n_curr bytes, 1 where curr.landmarks_[i] && has_observation() on entry
+ *                   (projection.cc:164); NULL = none
+ *   direction       assume_forward / assume_backward / neither (projection.cc:101-107,139-153)
+ *   matched_query   out, n_curr: index of the query whose landmark ends up in
+ *                   curr.landmarks_[i] through this call, or -1
+ * *num_matches is the function's return value. */
+int ovs_match_current_and_last_frames(const ovs_frame_view* curr, const ovs_proj_queries* q,
+                                      const uint8_t* curr_occupied, float margin, int direction,
+                                      int last_num_scale_levels, float lowe_ratio, int check_orientation,
+                                      int32_t* matched_query, uint32_t* num_matches, int device);
+
+/* projection::match_frame_and_landmarks (projection.cc:11-82).  Queries = local landmarks with
+ * reproj_in_tracking_, x_right_in_tracking_, scale_level_in_tracking_; `valid` folds
+ * is_observable_in_tracking_ && !will_be_erased().  Levels searched: [pred-1, pred]. */
+int ovs_match_frame_and_landmarks(const ovs_frame_view* frm, const ovs_proj_queries* q,
+                                  const uint8_t* frm_occupied, float margin, float lowe_ratio,
+                                  int32_t* matched_query, uint32_t* num_matches, int device);
+
+/* projection::match_frame_and_keyframe (projection.cc:211-313): queries = keyframe landmarks
+ * that pass the visibility / distance gates (folded into `valid`), levels [pred-1, pred+1],
+ * candidates skipped when curr.landmarks_[i] is non-null (`curr_occupied`), threshold
+ * hamm_dist_thr, rotation check against the keyframe keypoint angles. */
+int ovs_match_frame_and_keyframe(const ovs_frame_view* curr, const ovs_proj_queries* q,
+                                 const uint8_t* curr_occupied, float margin, uint32_t hamm_dist_thr,
+                                 int check_orientation,
+                                 int32_t* matched_query, uint32_t* num_matches, int device);
+
+/* projection::match_by_Sim3_transform (projection.cc:315-413): window without level gate in
+ * get_keypoints_in_cell, then the unsigned `scale_level < pred - 1 || pred < scale_level` gate
+ * of projection.cc:390 (pred == 0 rejects every candidate), threshold HAMMING_DIST_THR_LOW.
+ * keyfrm_occupied = matched_lms_in_keyfrm[i] != nullptr on entry. */
+int ovs_match_by_sim3_transform(const ovs_frame_view* keyfrm, const ovs_proj_queries* q,
+                                const uint8_t* keyfrm_occupied, float margin,
+                                int32_t* matched_query, uint32_t* num_matches, int device);
+
+/* One direction of projection::match_keyframes_mutually (projection.cc:457-533 / 540-616):
+ * per query the best keypoint index (<= HAMMING_DIST_THR_HIGH, same unsigned level gate, no
+ * exclusion between queries) or -1.  The cross-check of projection.cc:619-631 is
+ * ovs_cross_check below. */
+int ovs_match_keyframe_one_way(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, float margin,
+                               int32_t* best_idx_of_query, int device);
+/* projection.cc:619-631: keeps i -> idx2 only if idx2 -> i.  out_idx2_of_1[i] = idx2 or -1. */
+int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, int n2,
+                    int32_t* out_idx2_of_1, uint32_t* num_matches);
+
+/* ------------------------------------------------------------------------------------------ */
+/* match::stereo                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct ovs_image_view {
+    const uint8_t* data;
+    int32_t width, height;
+    size_t stride;
+} ovs_image_view;
+
+/* match::stereo::compute (src/openvslam/match/stereo.cc:18-113) including
+ * get_right_keypoint_indices_in_each_row (:115-142), find_closest_keypoints_in_stereo
+ * (:144-177), compute_subpixel_disparity (:179-250) and the median rejection (:96-112).
+ *   left_pyr / right_pyr   num_levels host images each (image_pyramid_ of the two extractors)
+ *   keypts / descs         distorted keypoints (keypts_, not undistorted) and descriptors
+ *   stereo_x_right, depths out, n_left floats each, -1 = no match. */
+int ovs_stereo_compute(const ovs_image_view* left_pyr, const ovs_image_view* right_pyr, int num_levels,
+                       const ovs_keypoint* keypts_left, int n_left,
+                       const ovs_keypoint* keypts_right, int n_right,
+                       const uint8_t* descs_left, const uint8_t* descs_right,
+                       const float* scale_factors, const float* inv_scale_factors,
+                       float focal_x_baseline, float true_baseline,
+                       float* stereo_x_right, float* depths, int device);
+
+/* ------------------------------------------------------------------------------------------ */
+/* match::robust, match::bow_tree                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* robust::brute_force_match (src/openvslam/match/robust.cc:209-315).
+ *   descs_1/angles_1  frame keypoints (n1); descs_2/angles_2 keyframe keypoints (n2)
+ *   valid_2           n2 bytes: lms_2[i] && !will_be_erased() (robust.cc:234-240)
+ *   matches           out, pairs (idx_1, idx_2) ascending in idx_1, capacity n1 pairs
+ * *num_matches is the function's return value (== number of pairs). */
+int ovs_brute_force_match(const uint8_t* descs_1, const float* angles_1, int n1,
+                          const uint8_t* descs_2, const float* angles_2, const uint8_t* valid_2, int n2,
+                          float lowe_ratio, int check_orientation,
+                          int32_t* matches, uint32_t* num_matches, int device);
+
+/* BoW feature vectors (DBoW2::FeatureVector = std::map<node id, std::vector<keypoint idx>>,
+ * src/openvslam/match/bow_tree.cc:25-35) flattened in ascending node-id order:
+ * node n holds indices[offsets[n] .. offsets[n+1]). */
+typedef struct ovs_bow_feat_vec {
+    int32_t num_nodes;
+    const uint32_t* node_ids; /* ascending */
+    const uint32_t* offsets;  /* num_nodes + 1 */
+    const uint32_t* indices;
+} ovs_bow_feat_vec;
+
+/* bow_tree::match_frame_and_keyframe (src/openvslam/match/bow_tree.cc:16-122).
+ *   valid_kf   keyfrm_lms[i] && !will_be_erased();  matched_kf_idx_in_frm out, n_frm: keyframe
+ *   keypoint index whose landmark lands in matched_lms_in_frm[i], or -1. */
+int ovs_bow_match_frame_and_keyframe(const ovs_bow_feat_vec* kf_vec, const uint8_t* kf_descs,
+                                     const float* kf_angles, const uint8_t* valid_kf, int n_kf,
+                                     const ovs_bow_feat_vec* frm_vec, const uint8_t* frm_descs,
+                                     const float* frm_angles, int n_frm,
+                                     float lowe_ratio, int check_orientation,
+                                     int32_t* matched_kf_idx_in_frm, uint32_t* num_matches, int device);
+
+/* bow_tree::match_keyframes (bow_tree.cc:124-246): matched_idx2_in_kf1 out, n1: index in
+ * keyframe 2 whose landmark lands in matched_lms_in_keyfrm_1[i], or -1. */
+int ovs_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1, const float* angles_1,
+                            const uint8_t* valid_1, int n1,
+                            const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2, const float* angles_2,
+                            const uint8_t* valid_2, int n2,
+                            float lowe_ratio, int check_orientation,
+                            int32_t* matched_idx2_in_kf1, uint32_t* num_matches, int device);
+
+/* robust::match_for_triangulation (src/openvslam/match/robust.cc:18-172).  The epipolar gates
+ * are evaluated in double exactly as robust.cc:106-121,317-335:
+ *   bearings_1/2     n x 3 doubles; E_12 row-major 3x3; epipole_in_2 = reproject_to_bearing of
+ *                    camera centre 1 into keyframe 2 (robust.cc:25-29)
+ *   has_lm_1/2       assoc landmark non-null (those keypoints are skipped, robust.cc:64,83)
+ *   stereo_x_right_1/2  may be NULL (monocular: all < 0)
+ *   pairs            out, (idx_1, idx_2) ascending idx_1, capacity n1 pairs. */
+int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
+                                const ovs_keypoint* undist_keypts_1, const double* bearings_1,
+                                const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,
+                                const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2,
+                                const ovs_keypoint* undist_keypts_2, const double* bearings_2,
+                                const float* stereo_x_right_2, const uint8_t* has_lm_2, int n2,
+                                const double* E_12, const double* epipole_in_2,
+                                const float* scale_factors_1, int num_scale_levels_1,
+                                int check_orientation,
+                                uint32_t* pairs, uint32_t* num_matches, int device);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Keyframe-database brute-force search (relocalisation over a descriptor database)           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* A device-resident descriptor database: rows of 32 bytes, row r belongs to keyframe
+ * r / keypts_per_keyframe.  No counterpart object in the reference, which only brute-forces one
+ * frame against one keyframe (robust.cc:250-268); the selection rule (strict <, first index wins,
+ * best and second best) is that loop's. */
+typedef struct ovs_desc_db ovs_desc_db;
+int ovs_desc_db_create(int device, ovs_desc_db** out);
+void ovs_desc_db_destroy(ovs_desc_db* db);
+/* Replaces the contents with n_rows host descriptors (copied). global_row_offset is added to
+ * every reported row index (shard base when the database is partitioned over processes). */
+int ovs_desc_db_upload(ovs_desc_db* db, const uint8_t* descs, int64_t n_rows, int64_t global_row_offset);
+/* Adopts a device buffer the caller keeps alive (no copy). */
+int ovs_desc_db_attach_dev(ovs_desc_db* db, const uint8_t* d_descs, int64_t n_rows, int64_t global_row_offset);
+
+/* One search result: distance and global row of the best and second-best database rows. */
+typedef struct ovs_knn2 {
+    uint32_t dist[2]; /* 256 where absent */
+    int64_t row[2];   /* -1 where absent  */
+} ovs_knn2;
+
+/* Top-2 over the database for nq query descriptors (host query/result buffers). */
+int ovs_desc_db_search(ovs_desc_db* db, const uint8_t* queries, int nq, ovs_knn2* out);
+/* Device buffers, enqueued on `stream`. */
+int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream);
+/* Merges n_lists per-shard results (list-major: lists[s*nq + q]) into out[q] with the
+ * lexicographic (dist, row) order, i.e. the serial strict-< scan over the whole database. */
+int ovs_knn2_merge(const ovs_knn2* lists, int n_lists, int nq, ovs_knn2* out);
+int ovs_knn2_merge_dev(const ovs_knn2* d_lists, int n_lists, int nq, ovs_knn2* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Batched extract + match on resident frames (offline sequences)                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* For every frame f >= 1 of the batch last extracted with ovs_orb_extract_batch_dev (outputs
+ * d_kps/d_desc/d_counts as written by that call), runs projection::match_current_and_last_frames
+ * (projection.cc:84-209) with frame f as `curr` and frame f-1 as `last`, every last keypoint
+ * carrying a landmark whose descriptor is its own and whose reprojection is given by the caller:
+ *   d_reproj_xy  n_frames x cap x 2 floats: reprojection of last-frame keypoint i into frame f
+ *                stored at [f][i]; entries with x < -1e30 are treated as not in the image
+ *   undistorted keypoints are the extracted ones (zero-distortion camera), monocular
+ *   d_matched    out, n_frames x cap int32: per curr keypoint the last-frame index or -1
+ *   d_num_matches out, n_frames uint32 (entry 0 is 0). */
+int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_t* d_desc,
+                                         const int32_t* d_counts, int n_frames, int cap,
+                                         const float* d_reproj_xy, const ovs_grid* grid,
+                                         const float* scale_factors, int num_scale_levels,
+                                         float margin, int check_orientation,
+                                         int32_t* d_matched, uint32_t* d_num_matches,
+                                         int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* OVS_H */

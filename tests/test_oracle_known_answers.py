@@ -1,0 +1,192 @@
+"""Pins the CPU oracle against every known-answer vector the reference's own unit tests hold for
+the hot path (the reference's tests are gtest programs that need OpenCV; their inputs and expected
+values are restated here)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from openvslam_amd import _abi as A
+
+L = oracle.lib()
+
+
+def _desc(byte):
+    return np.full(32, byte, dtype=np.uint8)
+
+
+# ---- test/openvslam/match/base.cc:11-57 ------------------------------------------------------
+@pytest.mark.parametrize("a,b,expected", [(0x55, 0x55, 0), (0x55, 0xAA, 256), (0x66, 0x3C, 128)])
+def test_hamming_known_answers(a, b, expected):
+    da, db = _desc(a), _desc(b)
+    assert L.ovo_hamming_32(A.ptr(da, A.u8p), A.ptr(db, A.u8p)) == expected
+    assert L.ovo_hamming_64(A.ptr(da, A.u8p), A.ptr(db, A.u8p)) == expected
+
+
+def test_hamming_random_vs_numpy():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (200, 32), dtype=np.uint8)
+    out = np.zeros(200, dtype=np.uint32)
+    oracle.check(L.ovo_hamming_pairs(A.ptr(a, A.u8p), A.ptr(b, A.u8p), 200, A.ptr(out, A.u32p)))
+    ref = np.unpackbits(a ^ b, axis=1).sum(axis=1)
+    assert np.array_equal(out, ref)
+    for i in range(20):
+        assert L.ovo_hamming_64(A.ptr(a[i], A.u8p), A.ptr(b[i], A.u8p)) == ref[i]
+
+
+# ---- test/openvslam/match/angle_checker.cc:12-180 --------------------------------------------
+ANGLE_CASES = [(34.8, 35), (34.9, 35), (35.0, 35), (35.1, 35), (35.2, 35),
+               (323.8, 324), (323.9, 324), (324.1, 324), (324.2, 324),
+               (126.9, 127), (127.0, 127), (127.1, 127),
+               (0.0, 0), (90.0, 60), (180.0, 180), (270.0, 270)]
+
+
+def _angle_partition(num_bins_thr):
+    c = L.ovo_angle_checker_create(30, num_bins_thr)
+    assert c
+    for ang, m in ANGLE_CASES:
+        L.ovo_angle_checker_append(c, ang, m)
+    buf = np.zeros(64, dtype=np.int32)
+    nv = L.ovo_angle_checker_valid(c, A.ptr(buf, A.i32p), 64)
+    valid = buf[:nv].tolist()
+    ni = L.ovo_angle_checker_invalid(c, A.ptr(buf, A.i32p), 64)
+    invalid = buf[:ni].tolist()
+    L.ovo_angle_checker_destroy(c)
+    return valid, invalid
+
+
+@pytest.mark.parametrize("thr,valid_set", [(1, {35}), (2, {35, 324}), (3, {35, 324, 127}),
+                                           (30, {35, 324, 127, 0, 60, 180, 270})])
+def test_angle_checker_partitions(thr, valid_set):
+    valid, invalid = _angle_partition(thr)
+    every = {35, 324, 127, 0, 60, 180, 270}
+    assert valid and set(valid) == valid_set
+    assert set(invalid) == every - valid_set
+    assert len(valid) + len(invalid) == len(ANGLE_CASES)
+
+
+def test_angle_checker_asserts():
+    assert L.ovo_angle_checker_create(30, 31) is None  # assert(num_bins_thr_ <= histogram_length_)
+    for ok in (3, 30):
+        c = L.ovo_angle_checker_create(30, ok)
+        assert c
+        L.ovo_angle_checker_destroy(c)
+
+
+# ---- test/openvslam/feature/orb_params.cc:152-196 --------------------------------------------
+@pytest.mark.parametrize("num_levels,scale", [(10, 1.26), (8, 1.2), (1, 1.2), (5, 2.0)])
+def test_scale_tables(num_levels, scale):
+    sf = oracle.scale_table("scale_factors", num_levels, scale)
+    isf = oracle.scale_table("inv_scale_factors", num_levels, scale)
+    sig = oracle.scale_table("level_sigma_sq", num_levels, scale)
+    isig = oracle.scale_table("inv_level_sigma_sq", num_levels, scale)
+    s = float(np.float32(scale))
+    for lvl in range(num_levels):
+        # EXPECT_FLOAT_EQ = within 4 ulp
+        assert sf[lvl] == pytest.approx(np.float32(s ** lvl), rel=4 * 2 ** -23)
+        assert isf[lvl] == pytest.approx(np.float32(s ** -lvl), rel=4 * 2 ** -23)
+        assert sig[lvl] == pytest.approx(np.float32(s ** (2 * lvl)), rel=4 * 2 ** -23)
+        assert isig[lvl] == pytest.approx(np.float32(s ** (-2 * lvl)), rel=4 * 2 ** -23)
+
+
+# ---- test/openvslam/feature/orb_params.cc:62-150 (mask rectangle validation) ------------------
+@pytest.mark.parametrize("rect,msg", [([0.5, 0.2, 0.0, 1.0], "x_max must be greater than x_min"),
+                                      ([0.2, 0.2, 0.0, 1.0], "x_max must be greater than x_min"),
+                                      ([0.0, 1.0, 0.7, 0.3], "y_max must be greater than x_min"),
+                                      ([0.0, 1.0, 0.3, 0.3], "y_max must be greater than x_min")])
+def test_mask_rect_validation(rect, msg):
+    p = A.make_orb_params(mask_rects=[rect])
+    h = C.c_void_p()
+    rc = L.ovo_orb_create(p.ref(), C.byref(h))
+    assert rc == A.OVS_ERR_INVALID_ARGUMENT
+    assert L.ovo_last_error().decode() == msg
+
+
+def test_mask_rect_valid():
+    p = A.make_orb_params(mask_rects=[[0.0, 1.0, 0.0, 0.1], [0.2, 0.5, 0.3, 0.9]])
+    h = C.c_void_p()
+    assert L.ovo_orb_create(p.ref(), C.byref(h)) == 0
+    L.ovo_orb_destroy(h)
+
+
+# ---- test/openvslam/util/trigonometric.cc:8-20 -----------------------------------------------
+def test_trig_tolerance():
+    for k in range(0, 3601):
+        deg = k * 0.1
+        rad = np.float32(deg * math.pi / 180.0)
+        assert abs(L.ovo_cos(rad) - math.cos(rad)) < 1e-3
+        assert abs(L.ovo_sin(rad) - math.sin(rad)) < 1e-3
+
+
+# ---- test/openvslam/data/common_get_cell_indices.cc:59-111 (zero-distortion camera) ----------
+def _cam_2000x1000():
+    # perspective camera without distortion: image bounds are the image rectangle
+    return A.make_grid(0.0, 0.0, 2000.0, 1000.0)
+
+
+def _cell(g, x, y):
+    cx, cy = C.c_int(-1), C.c_int(-1)
+    found = L.ovo_get_cell_indices(C.byref(g), np.float32(x), np.float32(y), C.byref(cx), C.byref(cy))
+    return found, cx.value, cy.value
+
+
+def test_get_cell_indices_valid_cases_2():
+    g = _cam_2000x1000()
+    eps = np.float32(0.01)
+    cw, ch = 1.0 / g.inv_cell_width, 1.0 / g.inv_cell_height
+    for ix in range(64):
+        for iy in range(48):
+            corners = [(np.float32(ix * cw + eps), np.float32(iy * ch + eps)),
+                       (np.float32((ix + 1) * cw - eps), np.float32(iy * ch + eps)),
+                       (np.float32(ix * cw + eps), np.float32((iy + 1) * ch - eps)),
+                       (np.float32((ix + 1) * cw - eps), np.float32((iy + 1) * ch - eps))]
+            for x, y in corners:
+                assert _cell(g, x, y) == (1, ix, iy)
+
+
+def test_get_cell_indices_corners_and_invalid():
+    # valid_cases_1 / invalid_cases of the reference use a distorted camera whose bounds come from
+    # cv::undistortPoints; the same corner / edge pattern is applied to the undistorted bounds here
+    g = _cam_2000x1000()
+    eps = 0.01
+    assert _cell(g, g.min_x, g.min_y) == (1, 0, 0)
+    assert _cell(g, g.max_x - eps, g.min_y) == (1, 63, 0)
+    assert _cell(g, g.min_x, g.max_y - eps) == (1, 0, 47)
+    assert _cell(g, g.max_x - eps, g.max_y - eps) == (1, 63, 47)
+    assert _cell(g, 1000.0, g.min_y)[0:2] == (1, 32) or _cell(g, 1000.0, g.min_y)[0:2] == (1, 31)
+    for x, y in [(g.min_x - eps, g.min_y - eps), (g.max_x, g.min_y - eps), (g.min_x - eps, g.max_y),
+                 (g.max_x, g.max_y), (1000.0, g.min_y - eps), (1000.0, g.max_y), (g.min_x - eps, 500.0),
+                 (g.max_x, 500.0)]:
+        assert _cell(g, x, y)[0] == 0
+
+
+# ---- OpenCV helper semantics ------------------------------------------------------------------
+def test_cv_round_floor_ceil():
+    assert [L.ovo_cv_round_f(v) for v in (0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 2.5001)] == [0, 2, 2, 0, -2, 2, 3]
+    assert [L.ovo_cv_round_d(v) for v in (0.5, 1.5, 2.5, -2.5)] == [0, 2, 2, -2]
+    assert [L.ovo_cv_floor_f(v) for v in (1.0, 1.9, -0.1, -1.0, -1.1)] == [1, 1, -1, -1, -2]
+    assert [L.ovo_cv_ceil_f(v) for v in (1.0, 1.1, -0.1, -1.0, -1.9)] == [1, 2, 0, -1, -1]
+    assert [L.ovo_cv_ceil_d(v) for v in (150.5, 150.0)] == [151, 150]
+
+
+def test_fast_atan2_accuracy():
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        y, x = rng.normal(size=2) * 1e4
+        a = L.ovo_fast_atan2(np.float32(y), np.float32(x))
+        ref = math.degrees(math.atan2(np.float32(y), np.float32(x))) % 360.0
+        d = abs(a - ref)
+        assert min(d, 360 - d) < 0.3
+        assert 0.0 <= a <= 360.0
+    assert L.ovo_fast_atan2(0.0, 0.0) == 0.0
+    assert L.ovo_fast_atan2(0.0, 1.0) == 0.0
+    assert abs(L.ovo_fast_atan2(1.0, 0.0) - 90.0) < 1e-3
+
+
+def test_gaussian_kernel():
+    k = np.zeros(7, dtype=np.int32)
+    L.ovo_gaussian_kernel_7_q8(A.ptr(k, A.i32p))
+    assert k.tolist() == [18, 34, 49, 55, 49, 34, 18]
