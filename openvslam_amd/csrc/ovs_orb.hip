@@ -1,0 +1,1736 @@
+// ovs_orb.hip -- ORB extractor for gfx950: image pyramid, per-cell FAST-9/16 + NMS, quadtree
+// keypoint distribution, intensity-centroid orientation, 7x7 Gaussian blur and rotated-BRIEF
+// descriptors, batched over frames.  Replaces feature::orb_extractor::extract()
+// (src/openvslam/feature/orb_extractor.cc:68-144) and everything it calls.
+//
+// Pipeline per batch (all launches on one stream, no host synchronisation in between):
+//   k_resize_linear   x (levels-1)   level k from level k-1        (orb_extractor.cc:263-272)
+//   k_fast_cells      x 1            one workgroup per 64-px cell  (orb_extractor.cc:274-369)
+//   k_gauss7          x 1            all levels, all frames        (orb_extractor.cc:132-133)
+//   k_quadtree        x 1            one workgroup per (frame, level) (orb_extractor.cc:398-590)
+//   k_orient_desc     x 1            one wavefront per keypoint    (orb_extractor.cc:592-702)
+//
+// Data layout in HBM (per handle, sized for the largest batch seen):
+//   pyramid   levels 1..L-1, [level][frame][h_l][pitch_l] u8, pitch_l = w_l rounded up to 64
+//             (level 0 is the caller's image and is read in place, as orb_extractor.cc:264 does)
+//   blurred   levels 0..L-1, same layout
+//   slots     [frame][cell][1024] u32  FAST survivors of one cell in raster order, packed
+//             x | y << 12 | score << 24 in border-relative level coordinates; 1024 is the exact
+//             maximum 3x3 non-maximum suppression leaves in a 64 x 64 window
+//   cand      [frame][level][cells_l * 1024] dense candidates in the reference's order
+//             (cells row-major, raster inside a cell): xy and (response << 24 | quadtree node)
+//   lvl_*     [frame][sum ncap_l] per-level keypoints in quadtree list order + [frame][L] counts
+#include "ovs_internal.h"
+#include "orb_pattern.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int kMaxLevels = 16;
+constexpr int kBorder = 19;     // orb_patch_radius_, orb_extractor.h:133
+constexpr int kCell = 64;       // cell_size, orb_extractor.cc:283
+constexpr int kOverlap = 6;     // overlap, orb_extractor.cc:282
+constexpr int kSlotsPerCell = 1024;
+constexpr int kHalfPatch = 15;  // fast_half_patch_size_, orb_extractor.h:130
+constexpr int kQtThreads = 512;
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+struct level_geom {
+    int w, h;
+    int pitch;            // row pitch of the library-owned planes of this level
+    long long pyr_off;    // byte offset of the level inside one frame's pyramid block (levels >= 1)
+    long long blur_off;   // byte offset inside one frame's blurred block
+    int cells_x, cells_y; // num_cols, num_rows of orb_extractor.cc:299-300
+    int cell_base;        // first flattened cell index of the level
+    int quota;            // num_keypts_per_level_
+    int ncap;             // quadtree node capacity
+    int kp_base;          // first slot of the level in the per-frame level-keypoint arrays
+    long long cand_base;  // first dense candidate slot of the level inside a frame
+    int nx, ny;           // initial node grid, orb_extractor.cc:486-499
+    double delta_x, delta_y;
+    float scale;          // scale_factors_[level]
+    float patch_size;     // (float)(unsigned)(31 * scale), orb_extractor.cc:380,388
+    int tab_off;          // offset of the resize tables of this level in the table buffer
+    int area2x;           // cv::resize switches to INTER_AREA for an exact 2x reduction
+    int blur_tile_base, blur_tiles_x, blur_tiles_y;
+};
+
+struct plan_dev {
+    int num_levels;
+    int total_cells;
+    int total_blur_tiles;
+    int kp_total_cap;
+    int max_cells;
+    int max_ncap;
+    long long frame_pyr_bytes;
+    long long frame_blur_bytes;
+    long long frame_cand_cap;
+    int ini_thr, min_thr;
+    level_geom lv[kMaxLevels];
+};
+
+struct image_src {
+    const uint8_t* img0;  // level 0, caller-owned
+    long long row_stride0, frame_stride0;
+    uint8_t* pyr;         // levels >= 1
+    const uint8_t* mask;  // level-0 mask or nullptr
+    long long mask_stride;
+    int mask_w, mask_h;
+};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const plan_dev& p, const image_src& s, int frame, int level, long long& pitch) {
+    if (level == 0) {
+        pitch = s.row_stride0;
+        return s.img0 + frame * s.frame_stride0;
+    }
+    pitch = p.lv[level].pitch;
+    return s.pyr + frame * p.frame_pyr_bytes + p.lv[level].pyr_off;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Pyramid: cv::resize(INTER_LINEAR) for 8-bit single channel, fixed point with 11 coefficient bits.
+// Horizontal pass in int32 (S[sx] * a0 + S[sx + 1] * a1), vertical pass
+// (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.  Tables (source offsets and
+// coefficient pairs) are built on the host exactly as OpenCV builds xofs / ialpha / yofs / ibeta.
+// One thread produces four horizontally adjacent pixels and stores them as one dword.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, const int* __restrict__ tabs, int level) {
+    const level_geom& g = p.lv[level];
+    const level_geom& gs = p.lv[level - 1];
+    const int frame = blockIdx.z;
+    const int dx0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int dy = blockIdx.y * 4 + threadIdx.y;
+    if (dx0 >= g.w || dy >= g.h) {
+        return;
+    }
+    long long spitch;
+    const uint8_t* src = level_ptr(p, s, frame, level - 1, spitch);
+    uint8_t* dst = s.pyr + frame * p.frame_pyr_bytes + g.pyr_off;
+
+    u32 packed = 0;
+    if (g.area2x) {
+        const uint8_t* r0 = src + (long long)(2 * dy) * spitch;
+        const uint8_t* r1 = r0 + spitch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = dx0 + k;
+            if (dx < g.w) {
+                const int v = (r0[2 * dx] + r0[2 * dx + 1] + r1[2 * dx] + r1[2 * dx + 1] + 2) >> 2;
+                packed |= (u32)v << (8 * k);
+            }
+        }
+    }
+    else {
+        const int* xofs = tabs + g.tab_off;
+        const int* xab = xofs + g.w;
+        const int* yofs = xab + g.w;
+        const int* yab = yofs + g.h;
+        const int sy = yofs[dy];
+        const int sy0 = min(max(sy, 0), gs.h - 1);
+        const int sy1 = min(max(sy + 1, 0), gs.h - 1);
+        const int bb = yab[dy];
+        const int b0 = (short)(bb & 0xFFFF), b1 = (short)(bb >> 16);
+        const uint8_t* r0 = src + (long long)sy0 * spitch;
+        const uint8_t* r1 = src + (long long)sy1 * spitch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = dx0 + k;
+            if (dx < g.w) {
+                const int sx = xofs[dx];
+                const int sx1 = min(sx + 1, gs.w - 1);
+                const int aa = xab[dx];
+                const int a0 = (short)(aa & 0xFFFF), a1 = (short)(aa >> 16);
+                const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+                const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (u32)(v & 0xFF) << (8 * k);
+            }
+        }
+    }
+    *reinterpret_cast<u32*>(dst + (long long)dy * g.pitch + dx0) = packed;
+}
+
+// -------------------------------------------------------------------------------------------------
+// FAST-9/16 with non-maximum suppression, one workgroup per 64-px cell (window <= 70 x 70 with the
+// 6-px overlap, so the 64 x 64 interiors tile the bordered level exactly).
+//
+// For a ring x[0..15] around centre v, let lo = min over the 16 arcs of 9 contiguous pixels of the
+// arc maximum and hi = max over the arcs of the arc minimum.  A = max(v - lo, hi - v) is the
+// largest t + 1 for which the pixel is still a FAST-9 corner at threshold t, hence
+//   corner at threshold t  <=>  A - 1 >= t,   and OpenCV's cornerScore of a corner is A - 1
+// independent of the threshold it was detected with.  The score plane S = max(A - 1, 0) is
+// therefore computed once per pixel with no divergence, and both thresholds (initial, and the
+// minimum one when the cell stays empty, orb_extractor.cc:340-347) only differ in the
+// suppression pass: a pixel is kept iff S >= t and S > S' for all 8 neighbours with S' >= t.
+// Survivors are written in raster order (row ballots + prefix over rows).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+
+__device__ __forceinline__ int fast_score_9_16(const uint8_t* c, int stride) {
+    int x[16];
+    x[0] = c[3 * stride];
+    x[1] = c[3 * stride + 1];
+    x[2] = c[2 * stride + 2];
+    x[3] = c[stride + 3];
+    x[4] = c[3];
+    x[5] = c[-stride + 3];
+    x[6] = c[-2 * stride + 2];
+    x[7] = c[-3 * stride + 1];
+    x[8] = c[-3 * stride];
+    x[9] = c[-3 * stride - 1];
+    x[10] = c[-2 * stride - 2];
+    x[11] = c[-stride - 3];
+    x[12] = c[-3];
+    x[13] = c[stride - 3];
+    x[14] = c[2 * stride - 2];
+    x[15] = c[3 * stride - 1];
+    const int v = c[0];
+    // sliding window of 9 over the circular ring by doubling: 3, 3+3 -> 6 (overlap-free), 9
+    int mx3[16], mn3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mx3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+        mn3[k] = min3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    int lo = 255, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int amax = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+        const int amin = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+        lo = min(lo, amax);
+        hi = max(hi, amin);
+    }
+    const int a = max(v - lo, hi - v);
+    return max(a - 1, 0);
+}
+
+__device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, unsigned x, float scale) {
+    // is_in_mask of orb_extractor.cc:278-280: mask.at<uchar>(y * scale, x * scale) == 0
+    int my = (int)((float)y * scale);
+    int mx = (int)((float)x * scale);
+    my = min(max(my, 0), s.mask_h - 1);
+    mx = min(max(mx, 0), s.mask_w - 1);
+    return s.mask[(long long)my * s.mask_stride + mx] == 0;
+}
+
+__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts) {
+    __shared__ uint8_t tile[70 * 72];
+    __shared__ uint8_t score[66 * 68];
+    __shared__ u64 keepmask[64];
+    __shared__ int rowbase[65];
+    __shared__ int total;
+
+    const int frame = blockIdx.y;
+    int cell = blockIdx.x;
+    int level = 0;
+#pragma unroll 1
+    for (int l = 1; l < p.num_levels; ++l) {
+        if (cell >= p.lv[l].cell_base) {
+            level = l;
+        }
+    }
+    const level_geom& g = p.lv[level];
+    cell -= g.cell_base;
+    const int ci = cell / g.cells_x, cj = cell - ci * g.cells_x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long out_cell = (long long)frame * p.total_cells + g.cell_base + cell;
+
+    const int max_border_x = g.w - kBorder, max_border_y = g.h - kBorder;
+    const int min_x = kBorder + cj * kCell, min_y = kBorder + ci * kCell;
+    // cells the reference skips (orb_extractor.cc:310,323)
+    bool skip = (max_border_y - kOverlap <= min_y) || (max_border_x - kOverlap <= min_x);
+    const int max_x = min(min_x + kCell + kOverlap, max_border_x);
+    const int max_y = min(min_y + kCell + kOverlap, max_border_y);
+    if (!skip && s.mask) {
+        // orb_extractor.cc:332-337
+        skip = mask_is_zero(s, min_y, min_x, g.scale) || mask_is_zero(s, max_y, min_x, g.scale)
+               || mask_is_zero(s, min_y, max_x, g.scale) || mask_is_zero(s, max_y, max_x, g.scale);
+    }
+    const int tw = max_x - min_x, th = max_y - min_y;
+    const int iw = tw - 6, ih = th - 6;
+    if (skip || iw <= 0 || ih <= 0) {
+        if (tid == 0) {
+            cell_counts[out_cell] = 0;
+        }
+        return;
+    }
+
+    long long pitch;
+    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
+    for (int i = tid; i < th * 72; i += 256) {
+        const int r = i / 72, c = i - r * 72;
+        if (c < tw) {
+            tile[r * 72 + c] = img[(long long)(min_y + r) * pitch + min_x + c];
+        }
+    }
+    for (int i = tid; i < 66 * 68; i += 256) {
+        score[i] = 0;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < 16; ++chunk) {
+        const int r = chunk * 4 + wave, c = lane;
+        if (r < ih && c < iw) {
+            score[(r + 1) * 68 + c + 1] = (uint8_t)fast_score_9_16(&tile[(r + 3) * 72 + c + 3], 72);
+        }
+    }
+    __syncthreads();
+
+    int thr = min(max(p.ini_thr, 0), 255);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+        for (int chunk = 0; chunk < 16; ++chunk) {
+            const int r = chunk * 4 + wave, c = lane;
+            bool keep = false;
+            if (r < ih && c < iw) {
+                const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
+                const int sc = sp[0];
+                if (sc >= thr) {
+                    int m = 0;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (dy != 0 || dx != 0) {
+                                const int nb = sp[dy * 68 + dx];
+                                m = max(m, nb >= thr ? nb : 0);
+                            }
+                        }
+                    }
+                    keep = sc > m;
+                }
+            }
+            const u64 bits = __ballot(keep);
+            if (lane == 0) {
+                keepmask[r] = bits;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int cnt = __popcll(keepmask[lane]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                cnt += __shfl_xor(cnt, d);
+            }
+            if (lane == 0) {
+                total = cnt;
+            }
+        }
+        __syncthreads();
+        const int min_thr = min(max(p.min_thr, 0), 255);
+        if (total != 0 || pass == 1) {
+            break;
+        }
+        thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
+        __syncthreads();
+    }
+    if (total == 0) {
+        if (tid == 0) {
+            cell_counts[out_cell] = 0;
+        }
+        return;
+    }
+
+    if (s.mask) {
+        // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
+#pragma unroll 1
+        for (int chunk = 0; chunk < 16; ++chunk) {
+            const int r = chunk * 4 + wave;
+            const u64 bits = keepmask[r];
+            bool keep = (bits >> lane) & 1ull;
+            if (keep) {
+                const unsigned y = kBorder + ci * kCell + 3 + r;
+                const unsigned x = kBorder + cj * kCell + 3 + lane;
+                keep = !mask_is_zero(s, y, x, g.scale);
+            }
+            const u64 nb = __ballot(keep);
+            if (lane == 0) {
+                keepmask[r] = nb; // row r is only ever touched by this wave
+            }
+        }
+        __syncthreads();
+    }
+
+    if (wave == 0) {
+        const int cnt = __popcll(keepmask[lane]);
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d);
+            if (lane >= d) {
+                inc += t;
+            }
+        }
+        rowbase[lane] = inc - cnt;
+        if (lane == 63) {
+            rowbase[64] = inc;
+        }
+    }
+    __syncthreads();
+
+    u32* out = slots + out_cell * kSlotsPerCell;
+#pragma unroll 1
+    for (int chunk = 0; chunk < 16; ++chunk) {
+        const int r = chunk * 4 + wave;
+        const u64 bits = keepmask[r];
+        if ((bits >> lane) & 1ull) {
+            const int pos = rowbase[r] + __popcll(bits & ((1ull << lane) - 1ull));
+            const u32 x = cj * kCell + 3 + lane; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
+            const u32 y = ci * kCell + 3 + r;
+            out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + lane + 1] << 24);
+        }
+    }
+    if (tid == 0) {
+        cell_counts[out_cell] = rowbase[64];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// 7x7 Gaussian blur, sigma 2, BORDER_REFLECT_101, 8-bit: separable integer kernel
+// k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact int32 row pass, column pass
+// (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).  64 x 32 output tile per workgroup,
+// source tile with a 3-px halo and the row-pass result (<= 65535, kept as u16) staged in LDS.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) {
+        return p;
+    }
+    if (len == 1) {
+        return 0;
+    }
+    do {
+        if (p < 0) {
+            p = -p;
+        }
+        else {
+            p = 2 * len - 2 - p;
+        }
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+constexpr int kBlurTW = 64, kBlurTH = 32;
+
+__global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur) {
+    __shared__ uint8_t src[(kBlurTH + 6) * 72];
+    __shared__ unsigned short rowp[(kBlurTH + 6) * kBlurTW];
+
+    const int frame = blockIdx.y;
+    int t = blockIdx.x;
+    int level = 0;
+#pragma unroll 1
+    for (int l = 1; l < p.num_levels; ++l) {
+        if (t >= p.lv[l].blur_tile_base) {
+            level = l;
+        }
+    }
+    const level_geom& g = p.lv[level];
+    t -= g.blur_tile_base;
+    const int ty = t / g.blur_tiles_x, tx = t - ty * g.blur_tiles_x;
+    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+    const int tid = threadIdx.x;
+
+    long long pitch;
+    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
+    for (int i = tid; i < (kBlurTH + 6) * 72; i += 256) {
+        const int r = i / 72, c = i - r * 72;
+        if (c < kBlurTW + 6) {
+            const int sy = reflect101(y0 + r - 3, g.h);
+            const int sx = reflect101(x0 + c - 3, g.w);
+            src[i] = img[(long long)sy * pitch + sx];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        const int r = i / kBlurTW, c = i - r * kBlurTW;
+        const uint8_t* q = &src[r * 72 + c];
+        const int v = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
+        rowp[i] = (unsigned short)v;
+    }
+    __syncthreads();
+    uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off;
+    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
+        const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
+        const int y = y0 + r;
+        if (y >= g.h || x0 + c4 >= g.w) {
+            continue;
+        }
+        u32 packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned short* q = &rowp[r * kBlurTW + c4 + k];
+            const int v = 18 * (q[0] + q[6 * kBlurTW]) + 34 * (q[kBlurTW] + q[5 * kBlurTW])
+                          + 49 * (q[2 * kBlurTW] + q[4 * kBlurTW]) + 55 * q[3 * kBlurTW];
+            const int o = min((v + (1 << 15)) >> 16, 255);
+            packed |= (u32)o << (8 * k);
+        }
+        *reinterpret_cast<u32*>(dst + (long long)y * g.pitch + x0 + c4) = packed;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Quadtree keypoint distribution (orb_extractor.cc:398-590, orb_extractor_node.cc:6-50), one
+// workgroup per (frame, level).
+//
+// The serial algorithm keeps a std::list of nodes, each owning a vector of keypoints; here the
+// node list is an array in list order (node id == list position, double buffered in LDS) and every
+// candidate keypoint carries the id of the node it currently belongs to.  One sweep of the serial
+// loop ("split every non-leaf node, children pushed to the list front, parent erased") becomes:
+//   1. candidates vote into their node's four child counters (LDS atomics),
+//   2. an exclusive scan over the nodes in list order of the number of non-empty children gives
+//      each child its creation index s; the new list is [children in reverse creation order]
+//      followed by the untouched leaf nodes in their old order, i.e. child position = C - 1 - s,
+//   3. candidates move to their child's id.
+// The fill-up phase (orb_extractor.cc:444-472) sorts the splittable nodes created by the previous
+// pass by (keypoint count, node address) descending; node addresses are replaced by creation
+// order (later created first), which for nodes sitting at list positions 0..C-1 in reverse
+// creation order is "count descending, then list position ascending".  Splitting stops at the
+// first node in that order at which the list reaches the quota, found with a scan over the
+// sorted pool.  Finally each node emits its first keypoint of maximum response (atomicMax on
+// response << 24 | (2^24 - 1 - original index)).
+// -------------------------------------------------------------------------------------------------
+constexpr u32 kLeaf = 0x80000000u; // is_leaf_node_ (only set by initialize_nodes, orb_extractor.cc:545)
+constexpr u32 kPool = 0x40000000u; // member of the pool being processed in the current fill-up pass
+constexpr u32 kProc = 0x20000000u; // split in the current fill-up pass
+constexpr u32 kCnt = 0x00FFFFFFu;
+
+__device__ __forceinline__ int child_of(short4 b, int x, int y) {
+    const int hx = (b.z - b.x + 1) >> 1; // cvCeil((end - begin) / 2.0)
+    const int hy = (b.w - b.y + 1) >> 1;
+    return (b.x + hx <= x ? 1 : 0) + (b.y + hy <= y ? 2 : 0);
+}
+
+__device__ __forceinline__ short4 child_bounds(short4 b, int c) {
+    const short hx = (short)((b.z - b.x + 1) >> 1);
+    const short hy = (short)((b.w - b.y + 1) >> 1);
+    short4 r;
+    r.x = (c & 1) ? (short)(b.x + hx) : b.x;
+    r.z = (c & 1) ? b.z : (short)(b.x + hx);
+    r.y = (c & 2) ? (short)(b.y + hy) : b.y;
+    r.w = (c & 2) ? b.w : (short)(b.y + hy);
+    return r;
+}
+
+// In-place exclusive scan of a[0..n) in LDS by the whole workgroup; returns the total.
+__device__ u32 block_excl_scan(u32* a, int n, u32* red) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const int per = (n + nt - 1) / nt;
+    const int b = min(tid * per, n), e = min(b + per, n);
+    u32 sum = 0;
+    for (int i = b; i < e; ++i) {
+        sum += a[i];
+    }
+    u32 inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d);
+        if (lane >= d) {
+            inc += t;
+        }
+    }
+    __syncthreads(); // red may still be read by a previous call
+    if (lane == 63) {
+        red[wave] = inc;
+    }
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+    for (int w = 0; w < nwaves; ++w) {
+        const u32 v = red[w];
+        woff += (w < wave) ? v : 0;
+        tot += v;
+    }
+    u32 run = woff + inc - sum;
+    for (int i = b; i < e; ++i) {
+        const u32 v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    __syncthreads();
+    return tot;
+}
+
+__device__ __forceinline__ int nonzero4(const u32* c) {
+    return (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+}
+
+__global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* __restrict__ slots, const u32* __restrict__ cell_counts,
+                                                         u32* __restrict__ cand_xy, u32* __restrict__ cand_st,
+                                                         u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count) {
+    extern __shared__ u32 smem[];
+    const int level = blockIdx.x, frame = blockIdx.y;
+    const level_geom& g = p.lv[level];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const int ncap = p.max_ncap;
+
+    short4* nb_cur = reinterpret_cast<short4*>(smem);
+    short4* nb_nxt = nb_cur + ncap;
+    u32* nc_cur = reinterpret_cast<u32*>(nb_nxt + ncap);
+    u32* nc_nxt = nc_cur + ncap;
+    u32* cc = nc_nxt + ncap; // 4 * ncap child counters, later child ids
+    u32* t0 = cc + 4 * ncap;
+    u32* t1 = t0 + ncap;
+    u32* t2 = t1 + ncap;
+    u32* t3 = t2 + ncap;
+    u32* cellpref = t3 + ncap; // max_cells + 1
+    u32* red = cellpref + p.max_cells + 1; // 16
+    u32* sh = red + 16;                    // scalars
+
+    const int ncells = g.cells_x * g.cells_y;
+    const long long cell0 = (long long)frame * p.total_cells + g.cell_base;
+    u32* cxy = cand_xy + frame * p.frame_cand_cap + g.cand_base;
+    u32* cst = cand_st + frame * p.frame_cand_cap + g.cand_base;
+    const int quota = g.quota;
+
+    for (int c = tid; c < ncells; c += nt) {
+        cellpref[c] = cell_counts[cell0 + c];
+    }
+    __syncthreads();
+    const int N = (int)block_excl_scan(cellpref, ncells, red);
+    if (tid == 0) {
+        cellpref[ncells] = N;
+    }
+    const int n0 = g.nx * g.ny;
+    for (int q = tid; q < n0; q += nt) {
+        t0[q] = 0;
+    }
+    __syncthreads();
+
+    // dense candidates in the reference's order + initial node of each (orb_extractor.cc:528-535)
+    for (int c = wave; c < ncells; c += nwaves) {
+        const int base = cellpref[c], cnt = cellpref[c + 1] - base;
+        const u32* src = slots + (cell0 + c) * kSlotsPerCell;
+        for (int e = lane; e < cnt; e += 64) {
+            const u32 v = src[e];
+            const u32 x = v & 0xFFFu, y = (v >> 12) & 0xFFFu, r = v >> 24;
+            const unsigned ix = (unsigned)((double)(float)x / g.delta_x);
+            const unsigned iy = (unsigned)((double)(float)y / g.delta_y);
+            const u32 ni = min(ix + iy * (unsigned)g.nx, (unsigned)(n0 - 1));
+            cxy[base + e] = x | (y << 16);
+            cst[base + e] = (r << 24) | ni;
+            atomicAdd(&t0[ni], 1u);
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < n0; q += nt) {
+        t1[q] = t0[q] != 0;
+    }
+    __syncthreads();
+    int S = (int)block_excl_scan(t1, n0, red);
+    for (int q = tid; q < n0; q += nt) {
+        const u32 cnt = t0[q];
+        if (cnt) {
+            const int ix = q % g.nx, iy = q / g.nx;
+            short4 b;
+            b.x = (short)(int)(g.delta_x * ix);
+            b.y = (short)(int)(g.delta_y * iy);
+            b.z = (short)(int)(g.delta_x * (ix + 1));
+            b.w = (short)(int)(g.delta_y * (iy + 1));
+            nb_cur[t1[q]] = b;
+            nc_cur[t1[q]] = cnt | (cnt == 1 ? kLeaf : 0u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) {
+        const u32 st = cst[i];
+        cst[i] = (st & 0xFF000000u) | t1[st & kCnt];
+    }
+    __syncthreads();
+
+    bool filled = false;
+    bool overflow = false;
+    int front = 0; // number of freshly created nodes at the head of the list
+
+    // ---- orb_extractor.cc:411-442: split every non-leaf node per sweep -------------------------
+    while (true) {
+        const int prev = S;
+        for (int i = tid; i < 4 * S; i += nt) {
+            cc[i] = 0;
+        }
+        if (tid == 0) {
+            sh[0] = 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += nt) {
+            const u32 n = cst[i] & kCnt;
+            if (!(nc_cur[n] & kLeaf)) {
+                const u32 xy = cxy[i];
+                atomicAdd(&cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < S; q += nt) {
+            const bool leaf = nc_cur[q] & kLeaf;
+            t0[q] = leaf ? 0 : nonzero4(&cc[4 * q]);
+            t1[q] = leaf ? 1 : 0;
+        }
+        __syncthreads();
+        const int C = (int)block_excl_scan(t0, S, red);
+        const int Lf = (int)block_excl_scan(t1, S, red);
+        const int Snew = C + Lf;
+        if (Snew > ncap) {
+            overflow = true;
+            break;
+        }
+        u32 local_pool = 0;
+        for (int q = tid; q < S; q += nt) {
+            if (nc_cur[q] & kLeaf) {
+                const int qn = C + t1[q];
+                nb_nxt[qn] = nb_cur[q];
+                nc_nxt[qn] = nc_cur[q];
+                cc[4 * q] = qn;
+            }
+            else {
+                const short4 b = nb_cur[q];
+                int r = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const u32 k = cc[4 * q + c];
+                    if (k) {
+                        const int qn = C - 1 - ((int)t0[q] + r);
+                        nb_nxt[qn] = child_bounds(b, c);
+                        nc_nxt[qn] = k;
+                        cc[4 * q + c] = qn;
+                        local_pool += k > 1;
+                        ++r;
+                    }
+                }
+            }
+        }
+        if (local_pool) {
+            atomicAdd(&sh[0], local_pool);
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += nt) {
+            const u32 st = cst[i];
+            const u32 n = st & kCnt;
+            u32 nn;
+            if (nc_cur[n] & kLeaf) {
+                nn = cc[4 * n];
+            }
+            else {
+                const u32 xy = cxy[i];
+                nn = cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)];
+            }
+            cst[i] = (st & 0xFF000000u) | nn;
+        }
+        const int pool = (int)sh[0];
+        __syncthreads();
+        {
+            short4* tb = nb_cur;
+            nb_cur = nb_nxt;
+            nb_nxt = tb;
+            u32* tc = nc_cur;
+            nc_cur = nc_nxt;
+            nc_nxt = tc;
+        }
+        S = Snew;
+        front = C;
+        if (quota <= S || S == prev) {
+            filled = true;
+            break;
+        }
+        if (quota < S + pool) {
+            filled = false;
+            break;
+        }
+    }
+
+    // ---- orb_extractor.cc:444-472: split the fullest nodes first until the quota is reached ----
+    while (!filled && !overflow) {
+        const int prev = S;
+        for (int q = tid; q < front; q += nt) {
+            t0[q] = (nc_cur[q] & kCnt) > 1;
+        }
+        __syncthreads();
+        const int P = (int)block_excl_scan(t0, front, red);
+        if (P == 0) {
+            break;
+        }
+        for (int q = tid; q < front; q += nt) {
+            if ((nc_cur[q] & kCnt) > 1) {
+                t1[t0[q]] = q;
+            }
+        }
+        __syncthreads();
+        // stable sort by count descending (rank by counting; the pool is at most a few hundred nodes)
+        for (int k = tid; k < P; k += nt) {
+            const u32 qk = t1[k];
+            const u32 ck = nc_cur[qk] & kCnt;
+            int rank = 0;
+            for (int j = 0; j < P; ++j) {
+                const u32 cj = nc_cur[t1[j]] & kCnt;
+                rank += (cj > ck) || (cj == ck && j < k);
+            }
+            t2[rank] = qk;
+            cc[4 * qk] = 0;
+            cc[4 * qk + 1] = 0;
+            cc[4 * qk + 2] = 0;
+            cc[4 * qk + 3] = 0;
+        }
+        if (tid == 0) {
+            sh[1] = P - 1;
+        }
+        __syncthreads();
+        for (int k = tid; k < P; k += nt) {
+            nc_cur[t2[k]] |= kPool;
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += nt) {
+            const u32 n = cst[i] & kCnt;
+            if (nc_cur[n] & kPool) {
+                const u32 xy = cxy[i];
+                atomicAdd(&cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < P; k += nt) {
+            t0[k] = nonzero4(&cc[4 * t2[k]]);
+        }
+        __syncthreads();
+        block_excl_scan(t0, P, red);
+        // first pool entry (in sorted order) at which the list reaches the quota
+        for (int k = tid; k < P; k += nt) {
+            const int created = (int)t0[k] + nonzero4(&cc[4 * t2[k]]);
+            if (quota <= S + created - (k + 1)) {
+                atomicMin(&sh[1], (u32)k);
+            }
+        }
+        __syncthreads();
+        const int kstar = (int)sh[1];
+        const int Cn = (int)t0[kstar] + nonzero4(&cc[4 * t2[kstar]]);
+        const int Snew = Cn + S - (kstar + 1);
+        const bool filled_now = quota <= Snew;
+        if (Snew > ncap) {
+            overflow = true;
+            break;
+        }
+        for (int k = tid; k <= kstar; k += nt) {
+            nc_cur[t2[k]] |= kProc;
+        }
+        __syncthreads();
+        for (int q = tid; q < S; q += nt) {
+            t3[q] = (nc_cur[q] & kProc) ? 0 : 1;
+        }
+        __syncthreads();
+        block_excl_scan(t3, S, red);
+        for (int k = tid; k <= kstar; k += nt) {
+            const u32 q = t2[k];
+            const short4 b = nb_cur[q];
+            int r = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 kk = cc[4 * q + c];
+                if (kk) {
+                    const int qn = Cn - 1 - ((int)t0[k] + r);
+                    nb_nxt[qn] = child_bounds(b, c);
+                    nc_nxt[qn] = kk;
+                    cc[4 * q + c] = qn;
+                    ++r;
+                }
+            }
+        }
+        for (int q = tid; q < S; q += nt) {
+            if (!(nc_cur[q] & kProc)) {
+                const int qn = Cn + (int)t3[q];
+                nb_nxt[qn] = nb_cur[q];
+                nc_nxt[qn] = nc_cur[q] & ~kPool;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < N; i += nt) {
+            const u32 st = cst[i];
+            const u32 n = st & kCnt;
+            u32 nn;
+            if (nc_cur[n] & kProc) {
+                const u32 xy = cxy[i];
+                nn = cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)];
+            }
+            else {
+                nn = Cn + t3[n];
+            }
+            cst[i] = (st & 0xFF000000u) | nn;
+        }
+        __syncthreads();
+        {
+            short4* tb = nb_cur;
+            nb_cur = nb_nxt;
+            nb_nxt = tb;
+            u32* tc = nc_cur;
+            nc_cur = nc_nxt;
+            nc_nxt = tc;
+        }
+        S = Snew;
+        front = Cn;
+        if (filled_now || quota <= S || S == prev) {
+            filled = true;
+        }
+    }
+
+    if (overflow) {
+        if (tid == 0) {
+            lvl_count[frame * p.num_levels + level] = -1;
+        }
+        return;
+    }
+
+    // ---- orb_extractor.cc:568-590: first keypoint of maximum response per node ------------------
+    for (int q = tid; q < S; q += nt) {
+        cc[q] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += nt) {
+        const u32 st = cst[i];
+        atomicMax(&cc[st & kCnt], (st & 0xFF000000u) | (0xFFFFFFu - (u32)i));
+    }
+    __syncthreads();
+    const long long ob = (long long)frame * p.kp_total_cap + g.kp_base;
+    for (int q = tid; q < S; q += nt) {
+        const u32 v = cc[q];
+        const u32 i = 0xFFFFFFu - (v & 0xFFFFFFu);
+        lvl_xy[ob + q] = cxy[i];
+        lvl_resp[ob + q] = (uint8_t)(v >> 24);
+    }
+    if (tid == 0) {
+        lvl_count[frame * p.num_levels + level] = S;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Orientation + descriptor, one wavefront per keypoint.
+//   ic_angle (orb_extractor.cc:608-631): lanes 0..30 own the 31 rows of the radius-15 disc, integer
+//   moments are reduced across the wave (exact in any order), cv::fastAtan2 in fp32 without fused
+//   multiply-add.
+//   compute_orb_descriptor (orb_extractor.cc:641-702): lane l evaluates pairs 4l..4l+3 of the
+//   pattern; util::cos / util::sin (util/trigonometric.h:17-46) and the rotated coordinates are
+//   evaluated in the reference's operation order in fp32, cvRound = round-half-even.
+// -------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024];
+__constant__ int c_umax[16];
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float scale = (float)(180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)DBL_EPSILON;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    }
+    else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) {
+        a = __fsub_rn(180.f, a);
+    }
+    if (y < 0) {
+        a = __fsub_rn(360.f, a);
+    }
+    return a;
+}
+
+__device__ __forceinline__ int cv_floor_f(float v) {
+    const int i = (int)v;
+    return i - (i > v);
+}
+
+__device__ __forceinline__ float trig_poly(float v) {
+    const float c1 = 0.99940307f, c2 = -0.49558072f, c3 = 0.03679168f;
+    const float v2 = __fmul_rn(v, v);
+    return __fadd_rn(c1, __fmul_rn(v2, __fadd_rn(c2, __fmul_rn(c3, v2))));
+}
+
+__device__ __forceinline__ float trig_cos(float v) {
+    const float PI = 3.14159265358979f;
+    const float PI_2 = PI / 2.0f;
+    const float TWO_PI = 2.0f * PI;
+    const float INV_TWO_PI = 1.0f / TWO_PI;
+    const float THREE_PI_2 = 3.0f * PI_2;
+    v = __fsub_rn(v, __fmul_rn((float)cv_floor_f(__fmul_rn(v, INV_TWO_PI)), TWO_PI));
+    v = (0.0f < v) ? v : -v;
+    if (v < PI_2) {
+        return trig_poly(v);
+    }
+    else if (v < PI) {
+        return -trig_poly(__fsub_rn(PI, v));
+    }
+    else if (v < THREE_PI_2) {
+        return -trig_poly(__fsub_rn(v, PI));
+    }
+    return trig_poly(__fsub_rn(TWO_PI, v));
+}
+
+__device__ __forceinline__ float trig_sin(float v) {
+    const float PI_2 = 3.14159265358979f / 2.0f;
+    return trig_cos(__fsub_rn(PI_2, v));
+}
+
+__global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, const uint8_t* __restrict__ blur,
+                                                     const u32* __restrict__ lvl_xy, const uint8_t* __restrict__ lvl_resp,
+                                                     const int* __restrict__ lvl_count,
+                                                     ovs_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
+                                                     int* __restrict__ out_counts, int cap) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6); // slot in the per-frame level-keypoint arrays
+    if (j >= p.kp_total_cap) {
+        return;
+    }
+    int level = 0;
+#pragma unroll 1
+    for (int l = 1; l < p.num_levels; ++l) {
+        if (j >= p.lv[l].kp_base) {
+            level = l;
+        }
+    }
+    const level_geom& g = p.lv[level];
+    const int slot = j - g.kp_base;
+    const int* counts = lvl_count + frame * p.num_levels;
+    int before = 0, total = 0;
+    bool bad = false;
+#pragma unroll 1
+    for (int l = 0; l < p.num_levels; ++l) {
+        const int c = counts[l];
+        bad |= c < 0;
+        before += (l < level) ? max(c, 0) : 0;
+        total += max(c, 0);
+    }
+    if (j == 0 && lane == 0) {
+        // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
+        out_counts[frame] = bad ? (int)0x80000000 : (total > cap ? -total : total);
+    }
+    if (bad || slot >= counts[level]) {
+        return;
+    }
+    const int oi = before + slot;
+    if (oi >= cap) {
+        return;
+    }
+
+    const long long li = (long long)frame * p.kp_total_cap + j;
+    const u32 xy = lvl_xy[li];
+    const int px = (int)(xy & 0xFFFF) + kBorder, py = (int)(xy >> 16) + kBorder; // pt += min_border, orb_extractor.cc:384-385
+    const int resp = lvl_resp[li];
+
+    long long pitch;
+    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
+
+    // ---- intensity centroid ----
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        const int v = lane - kHalfPatch;
+        const int d = c_umax[v < 0 ? -v : v];
+        const uint8_t* row = img + (long long)(py + v) * pitch + px;
+        int s0 = 0, s1 = 0;
+        for (int u = -d; u <= d; ++u) {
+            const int val = row[u];
+            s0 += val;
+            s1 += u * val;
+        }
+        m10 = s1;
+        m01 = v * s0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d);
+        m01 += __shfl_xor(m01, d);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- rotated BRIEF on the blurred level ----
+    const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
+    const float ca = trig_cos(arad), sa = trig_sin(arad);
+    const uint8_t* center = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)py * g.pitch + px;
+    const int step = g.pitch;
+    u32 nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int8_t* pp = &c_pattern[(lane * 4 + k) * 4];
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
+        const int v0 = center[r0 * step + c0];
+        const int v1 = center[r1 * step + c1];
+        nib |= (u32)(v0 < v1) << k;
+    }
+    // lane l holds bits 4l..4l+3 of the descriptor: gather 8 lanes into one dword
+    u32 word = nib << (4 * (lane & 7));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    word |= __shfl_xor(word, 4);
+    if ((lane & 7) == 0) {
+        reinterpret_cast<u32*>(out_desc + ((long long)frame * cap + oi) * 32)[lane >> 3] = word;
+    }
+    if (lane == 0) {
+        ovs_keypoint kp;
+        float fx = (float)px, fy = (float)py;
+        if (level != 0) {
+            fx = __fmul_rn(fx, g.scale); // correct_keypoint_scale, orb_extractor.cc:598-606
+            fy = __fmul_rn(fy, g.scale);
+        }
+        kp.x = fx;
+        kp.y = fy;
+        kp.size = g.patch_size;
+        kp.angle = angle;
+        kp.response = (float)resp;
+        kp.octave = level;
+        kp.class_id = -1;
+        out_kps[(long long)frame * cap + oi] = kp;
+    }
+}
+
+} // namespace
+
+// =================================================================================================
+// Host side
+// =================================================================================================
+struct ovs_orb {
+    int device = 0;
+    // orb_params
+    uint32_t max_num_keypts = 2000;
+    float scale_factor = 1.2f;
+    uint32_t num_levels = 8;
+    uint32_t ini_fast_thr = 20;
+    uint32_t min_fast_thr = 7;
+    std::vector<float> mask_rects; // 4 per rectangle
+
+    std::vector<float> scale_factors, inv_scale_factors, level_sigma_sq, inv_level_sigma_sq;
+    std::vector<uint32_t> num_keypts_per_level;
+    int u_max[16];
+
+    // plan for the current image size
+    int plan_w = 0, plan_h = 0;
+    plan_dev plan;
+    ovs::dev_buffer tabs;
+    bool constants_uploaded = false;
+
+    // rectangle mask (orb_extractor.cc:82-85: created once, for the size of the first image)
+    bool mask_is_initialized = false;
+    ovs::dev_buffer rect_mask;
+    int rect_mask_w = 0, rect_mask_h = 0;
+
+    // batch-capacity dependent buffers
+    int batch_cap = 0;
+    ovs::dev_buffer pyr, blur, slots, cell_counts, cand_xy, cand_st, lvl_xy, lvl_resp, lvl_count;
+    // staging for the single-frame host entry point
+    ovs::dev_buffer st_img, st_mask, st_kps, st_desc, st_count;
+    hipStream_t own_stream = nullptr;
+
+    // state of the last extraction (for the pyramid accessors)
+    const uint8_t* last_img0 = nullptr;
+    long long last_row_stride0 = 0, last_frame_stride0 = 0;
+    int last_frames = 0;
+};
+
+namespace {
+
+void orb_initialize(ovs_orb* h) {
+    // orb_extractor::initialize(), orb_extractor.cc:205-239
+    const uint32_t L = h->num_levels;
+    h->scale_factors.resize(L);
+    h->inv_scale_factors.resize(L);
+    h->level_sigma_sq.resize(L);
+    h->inv_level_sigma_sq.resize(L);
+    ovs_calc_scale_factors(L, h->scale_factor, h->scale_factors.data());
+    ovs_calc_inv_scale_factors(L, h->scale_factor, h->inv_scale_factors.data());
+    ovs_calc_level_sigma_sq(L, h->scale_factor, h->level_sigma_sq.data());
+    ovs_calc_inv_level_sigma_sq(L, h->scale_factor, h->inv_level_sigma_sq.data());
+
+    h->num_keypts_per_level.resize(L);
+    double desired_num_keypts_per_scale
+        = h->max_num_keypts * (1.0 - 1.0 / h->scale_factor)
+          / (1.0 - std::pow(1.0 / h->scale_factor, static_cast<double>(L)));
+    unsigned int total_num_keypts = 0;
+    for (unsigned int level = 0; level < L - 1; ++level) {
+        h->num_keypts_per_level.at(level) = std::round(desired_num_keypts_per_scale);
+        total_num_keypts += h->num_keypts_per_level.at(level);
+        desired_num_keypts_per_scale *= 1.0 / h->scale_factor;
+    }
+    h->num_keypts_per_level.at(L - 1) = std::max(static_cast<int>(h->max_num_keypts) - static_cast<int>(total_num_keypts), 0);
+
+    const int half = kHalfPatch;
+    std::vector<int> u_max(half + 2, 0);
+    const unsigned int vmax = std::floor(half * std::sqrt(2.0) / 2 + 1);
+    const unsigned int vmin = std::ceil(half * std::sqrt(2.0) / 2);
+    for (unsigned int v = 0; v <= vmax; ++v) {
+        u_max.at(v) = std::round(std::sqrt(static_cast<double>(half * half) - static_cast<double>(v * v)));
+    }
+    for (unsigned int v = half, v0 = 0; vmin <= v; --v) {
+        while (u_max.at(v0) == u_max.at(v0 + 1)) {
+            ++v0;
+        }
+        u_max.at(v) = v0;
+        ++v0;
+    }
+    for (int i = 0; i < 16; ++i) {
+        h->u_max[i] = u_max[i];
+    }
+    h->plan_w = h->plan_h = 0; // geometry depends on the parameters
+    h->constants_uploaded = false;
+}
+
+inline short saturate_short(float v) {
+    const int iv = static_cast<int>(lrintf(v));
+    return static_cast<short>(std::min(std::max(iv, -32768), 32767));
+}
+
+// xofs / ialpha (and yofs / ibeta) of cv::resize INTER_LINEAR, 8-bit fixed point path
+void resize_tables(int ssize, int dsize, bool clamp, int* ofs, int* coef) {
+    const double inv_scale = static_cast<double>(dsize) / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        float f = static_cast<float>((d + 0.5) * scale - 0.5);
+        int sidx = static_cast<int>(f);
+        sidx -= (sidx > f); // cvFloor
+        f -= sidx;
+        if (clamp) {
+            if (sidx < 0) {
+                f = 0;
+                sidx = 0;
+            }
+            if (sidx >= ssize - 1) {
+                f = 0;
+                sidx = ssize - 1;
+            }
+        }
+        ofs[d] = sidx;
+        const unsigned a0 = static_cast<unsigned short>(saturate_short((1.f - f) * 2048));
+        const unsigned a1 = static_cast<unsigned short>(saturate_short(f * 2048));
+        coef[d] = static_cast<int>(a0 | (a1 << 16));
+    }
+}
+
+bool is_area_fast_2x(int sw, int sh, int dw, int dh) {
+    const double scale_x = 1. / (static_cast<double>(dw) / sw);
+    const double scale_y = 1. / (static_cast<double>(dh) / sh);
+    const int iscale_x = static_cast<int>(lrint(scale_x));
+    const int iscale_y = static_cast<int>(lrint(scale_y));
+    return std::fabs(scale_x - iscale_x) < DBL_EPSILON && std::fabs(scale_y - iscale_y) < DBL_EPSILON
+           && iscale_x == 2 && iscale_y == 2;
+}
+
+size_t quadtree_lds_bytes(const plan_dev& p) {
+    // nb x2 (8 B), nc x2 (4 B), cc (16 B), t0..t3 (16 B) per node + cell prefix + scratch
+    return static_cast<size_t>(p.max_ncap) * (16 + 8 + 16 + 16) + static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
+}
+
+int build_plan(ovs_orb* h, int width, int height) {
+    if (h->plan_w == width && h->plan_h == height) {
+        return OVS_OK;
+    }
+    const int L = static_cast<int>(h->num_levels);
+    if (L > kMaxLevels) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 16 pyramid levels are not supported");
+    }
+    if (width > 4096 + 2 * kBorder || height > 4096 + 2 * kBorder) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "images larger than 4134 pixels per side are not supported");
+    }
+    plan_dev p;
+    std::memset(&p, 0, sizeof(p));
+    p.num_levels = L;
+    p.ini_thr = static_cast<int>(h->ini_fast_thr);
+    p.min_thr = static_cast<int>(h->min_fast_thr);
+    long long pyr_off = 0, blur_off = 0, cand_base = 0;
+    int cell_base = 0, kp_base = 0, tab_off = 0, blur_tile_base = 0;
+    std::vector<int> tabs;
+    for (int l = 0; l < L; ++l) {
+        level_geom& g = p.lv[l];
+        const double scale = h->scale_factors.at(l);
+        // orb_extractor.cc:267-268
+        g.w = l == 0 ? width : static_cast<int>(std::round(width * 1.0 / scale));
+        g.h = l == 0 ? height : static_cast<int>(std::round(height * 1.0 / scale));
+        if (g.w <= 2 * kBorder || g.h <= 2 * kBorder) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "image too small for the pyramid");
+        }
+        g.pitch = (g.w + 63) & ~63;
+        g.pyr_off = pyr_off;
+        if (l >= 1) {
+            pyr_off += static_cast<long long>(g.pitch) * g.h;
+        }
+        g.blur_off = blur_off;
+        blur_off += static_cast<long long>(g.pitch) * g.h;
+        const unsigned bw = g.w - 2 * kBorder, bh = g.h - 2 * kBorder;
+        g.cells_x = static_cast<int>(bw / kCell) + 1; // std::ceil(width / cell_size) + 1 with integer division
+        g.cells_y = static_cast<int>(bh / kCell) + 1;
+        g.cell_base = cell_base;
+        cell_base += g.cells_x * g.cells_y;
+        g.quota = static_cast<int>(h->num_keypts_per_level.at(l));
+        // initial nodes, orb_extractor.cc:480-499 (min_x == min_y == 19, so the `max_x - min_y`
+        // of the portrait branch equals the width)
+        const double ratio = static_cast<double>(bw) / bh;
+        if (ratio > 1) {
+            g.nx = static_cast<int>(static_cast<unsigned>(std::round(ratio)));
+            g.ny = 1;
+            g.delta_x = static_cast<double>(bw) / g.nx;
+            g.delta_y = bh;
+        }
+        else {
+            g.nx = 1;
+            g.ny = static_cast<int>(static_cast<unsigned>(std::round(1 / ratio)));
+            g.delta_x = bw;
+            g.delta_y = static_cast<double>(bh) / g.ny;
+        }
+        // list length bound: a sweep runs only while nodes + splittable <= quota, which caps the
+        // next list at 2 * quota; the first sweep yields at most 4 nodes per initial node; the
+        // fill-up phase overshoots by at most 3
+        g.ncap = std::max(2 * g.quota, 4 * g.nx * g.ny) + 8;
+        g.kp_base = kp_base;
+        kp_base += g.ncap;
+        g.cand_base = cand_base;
+        cand_base += static_cast<long long>(g.cells_x) * g.cells_y * kSlotsPerCell;
+        g.scale = h->scale_factors.at(l);
+        g.patch_size = static_cast<float>(static_cast<unsigned int>(31 * h->scale_factors.at(l)));
+        g.blur_tile_base = blur_tile_base;
+        g.blur_tiles_x = (g.w + kBlurTW - 1) / kBlurTW;
+        g.blur_tiles_y = (g.h + kBlurTH - 1) / kBlurTH;
+        blur_tile_base += g.blur_tiles_x * g.blur_tiles_y;
+        g.tab_off = tab_off;
+        g.area2x = 0;
+        if (l >= 1) {
+            const level_geom& gs = p.lv[l - 1];
+            g.area2x = is_area_fast_2x(gs.w, gs.h, g.w, g.h) ? 1 : 0;
+            tabs.resize(tab_off + 2 * g.w + 2 * g.h);
+            resize_tables(gs.w, g.w, true, tabs.data() + tab_off, tabs.data() + tab_off + g.w);
+            resize_tables(gs.h, g.h, false, tabs.data() + tab_off + 2 * g.w, tabs.data() + tab_off + 2 * g.w + g.h);
+            tab_off += 2 * g.w + 2 * g.h;
+        }
+        p.max_cells = std::max(p.max_cells, g.cells_x * g.cells_y);
+        p.max_ncap = std::max(p.max_ncap, g.ncap);
+    }
+    p.total_cells = cell_base;
+    p.total_blur_tiles = blur_tile_base;
+    p.kp_total_cap = kp_base;
+    p.frame_pyr_bytes = (pyr_off + 255) & ~255ll;
+    p.frame_blur_bytes = (blur_off + 255) & ~255ll;
+    p.frame_cand_cap = cand_base;
+    if (quadtree_lds_bytes(p) > 160 * 1024) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "keypoint quota per level too large for the on-chip quadtree");
+    }
+    OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(quadtree_lds_bytes(p))));
+    if (!tabs.empty()) {
+        int rc = h->tabs.reserve(tabs.size() * sizeof(int));
+        if (rc != OVS_OK) {
+            return rc;
+        }
+        OVS_HIP(hipMemcpy(h->tabs.ptr, tabs.data(), tabs.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    h->plan = p;
+    h->plan_w = width;
+    h->plan_h = height;
+    h->batch_cap = 0; // buffers depend on the geometry
+    return OVS_OK;
+}
+
+int ensure_buffers(ovs_orb* h, int n_frames) {
+    if (n_frames <= h->batch_cap) {
+        return OVS_OK;
+    }
+    const plan_dev& p = h->plan;
+    const size_t B = static_cast<size_t>(n_frames);
+    int rc;
+    if ((rc = h->pyr.reserve(std::max<size_t>(B * p.frame_pyr_bytes, 256))) != OVS_OK) return rc;
+    if ((rc = h->blur.reserve(B * p.frame_blur_bytes)) != OVS_OK) return rc;
+    if ((rc = h->slots.reserve(B * p.total_cells * kSlotsPerCell * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->cell_counts.reserve(B * p.total_cells * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->cand_xy.reserve(B * p.frame_cand_cap * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->cand_st.reserve(B * p.frame_cand_cap * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->lvl_xy.reserve(B * p.kp_total_cap * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->lvl_resp.reserve(B * p.kp_total_cap)) != OVS_OK) return rc;
+    if ((rc = h->lvl_count.reserve(B * p.num_levels * sizeof(int))) != OVS_OK) return rc;
+    h->batch_cap = n_frames;
+    return OVS_OK;
+}
+
+int ensure_rect_mask(ovs_orb* h, int width, int height) {
+    // orb_extractor.cc:82-85, :248-261.  The filled rectangle covers the closed box
+    // [x_min, x_max] x [y_min, y_max]; the anti-aliased rim cv::rectangle adds is non-zero and
+    // cannot be seen by the `== 0` test.
+    if (h->mask_is_initialized || h->mask_rects.empty()) {
+        return OVS_OK;
+    }
+    std::vector<uint8_t> m(static_cast<size_t>(width) * height, 255);
+    const unsigned cols = width, rows = height;
+    for (size_t r = 0; r + 3 < h->mask_rects.size(); r += 4) {
+        const unsigned int x_min = std::round(cols * h->mask_rects[r]);
+        const unsigned int x_max = std::round(cols * h->mask_rects[r + 1]);
+        const unsigned int y_min = std::round(rows * h->mask_rects[r + 2]);
+        const unsigned int y_max = std::round(rows * h->mask_rects[r + 3]);
+        const int x0 = std::max(static_cast<int>(x_min), 0), x1 = std::min(static_cast<int>(x_max), width - 1);
+        const int y0 = std::max(static_cast<int>(y_min), 0), y1 = std::min(static_cast<int>(y_max), height - 1);
+        for (int y = y0; y <= y1; ++y) {
+            for (int x = x0; x <= x1; ++x) {
+                m[static_cast<size_t>(y) * width + x] = 0;
+            }
+        }
+    }
+    int rc = h->rect_mask.reserve(m.size());
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(hipMemcpy(h->rect_mask.ptr, m.data(), m.size(), hipMemcpyHostToDevice));
+    h->rect_mask_w = width;
+    h->rect_mask_h = height;
+    h->mask_is_initialized = true;
+    return OVS_OK;
+}
+
+int upload_constants(ovs_orb* h) {
+    if (h->constants_uploaded) {
+        return OVS_OK;
+    }
+    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ovs_orb_pattern, 1024));
+    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->u_max, sizeof(int) * 16));
+    h->constants_uploaded = true;
+    return OVS_OK;
+}
+
+int validate_rects(const ovs_orb_params* params) {
+    // orb_params.cc:14-24
+    for (uint32_t i = 0; i < params->num_mask_rects; ++i) {
+        const float* v = params->mask_rects + 4 * i;
+        if (v[0] >= v[1]) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "x_max must be greater than x_min");
+        }
+        if (v[2] >= v[3]) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "y_max must be greater than x_min");
+        }
+    }
+    return OVS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ovs_orb_create(const ovs_orb_params* params, int device, ovs_orb** out) {
+    if (!params || !out) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    if (params->num_levels == 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "num_levels must be positive");
+    }
+    if (params->num_mask_rects && !params->mask_rects) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "mask_rects is null");
+    }
+    int rc = validate_rects(params);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return ovs::fail(OVS_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    }
+    if (device < 0 || device >= ndev) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    }
+    auto* h = new ovs_orb();
+    h->device = device;
+    h->max_num_keypts = params->max_num_keypts;
+    h->scale_factor = params->scale_factor;
+    h->num_levels = params->num_levels;
+    h->ini_fast_thr = params->ini_fast_thr;
+    h->min_fast_thr = params->min_fast_thr;
+    h->mask_rects.assign(params->mask_rects, params->mask_rects + 4 * static_cast<size_t>(params->num_mask_rects));
+    orb_initialize(h);
+    *out = h;
+    return OVS_OK;
+}
+
+void ovs_orb_destroy(ovs_orb* h) {
+    if (!h) {
+        return;
+    }
+    ovs::device_guard guard(h->device);
+    for (ovs::dev_buffer* b : {&h->tabs, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand_xy, &h->cand_st,
+                               &h->lvl_xy, &h->lvl_resp, &h->lvl_count, &h->st_img, &h->st_mask, &h->st_kps, &h->st_desc, &h->st_count}) {
+        b->release();
+    }
+    if (h->own_stream) {
+        (void)hipStreamDestroy(h->own_stream);
+    }
+    delete h;
+}
+
+uint32_t ovs_orb_get_max_num_keypoints(const ovs_orb* h) { return h->max_num_keypts; }
+int ovs_orb_set_max_num_keypoints(ovs_orb* h, uint32_t v) {
+    h->max_num_keypts = v;
+    orb_initialize(h);
+    return OVS_OK;
+}
+float ovs_orb_get_scale_factor(const ovs_orb* h) { return h->scale_factor; }
+int ovs_orb_set_scale_factor(ovs_orb* h, float v) {
+    h->scale_factor = v;
+    orb_initialize(h);
+    return OVS_OK;
+}
+uint32_t ovs_orb_get_num_scale_levels(const ovs_orb* h) { return h->num_levels; }
+int ovs_orb_set_num_scale_levels(ovs_orb* h, uint32_t v) {
+    if (v == 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "num_levels must be positive");
+    }
+    h->num_levels = v;
+    orb_initialize(h);
+    return OVS_OK;
+}
+uint32_t ovs_orb_get_initial_fast_threshold(const ovs_orb* h) { return h->ini_fast_thr; }
+int ovs_orb_set_initial_fast_threshold(ovs_orb* h, uint32_t v) {
+    h->ini_fast_thr = v; // no re-initialisation, orb_extractor.cc:177-179
+    h->plan.ini_thr = static_cast<int>(v);
+    return OVS_OK;
+}
+uint32_t ovs_orb_get_minimum_fast_threshold(const ovs_orb* h) { return h->min_fast_thr; }
+int ovs_orb_set_minimum_fast_threshold(ovs_orb* h, uint32_t v) {
+    h->min_fast_thr = v;
+    h->plan.min_thr = static_cast<int>(v);
+    return OVS_OK;
+}
+int ovs_orb_get_scale_factors(const ovs_orb* h, float* out) {
+    std::copy(h->scale_factors.begin(), h->scale_factors.end(), out);
+    return OVS_OK;
+}
+int ovs_orb_get_inv_scale_factors(const ovs_orb* h, float* out) {
+    std::copy(h->inv_scale_factors.begin(), h->inv_scale_factors.end(), out);
+    return OVS_OK;
+}
+int ovs_orb_get_level_sigma_sq(const ovs_orb* h, float* out) {
+    std::copy(h->level_sigma_sq.begin(), h->level_sigma_sq.end(), out);
+    return OVS_OK;
+}
+int ovs_orb_get_inv_level_sigma_sq(const ovs_orb* h, float* out) {
+    std::copy(h->inv_level_sigma_sq.begin(), h->inv_level_sigma_sq.end(), out);
+    return OVS_OK;
+}
+int ovs_orb_get_num_keypts_per_level(const ovs_orb* h, uint32_t* out) {
+    std::copy(h->num_keypts_per_level.begin(), h->num_keypts_per_level.end(), out);
+    return OVS_OK;
+}
+
+int ovs_orb_level_size(const ovs_orb* h, int width, int height, int level, int* w, int* hh) {
+    if (level < 0 || level >= static_cast<int>(h->num_levels)) {
+        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "level out of range");
+    }
+    const double scale = h->scale_factors.at(level);
+    *w = level == 0 ? width : static_cast<int>(std::round(width * 1.0 / scale));
+    *hh = level == 0 ? height : static_cast<int>(std::round(height * 1.0 / scale));
+    return OVS_OK;
+}
+
+int ovs_orb_keypoint_capacity(const ovs_orb* h, int width, int height) {
+    int total = 0;
+    for (uint32_t l = 0; l < h->num_levels; ++l) {
+        int w, hh;
+        ovs_orb_level_size(h, width, height, static_cast<int>(l), &w, &hh);
+        if (w <= 2 * kBorder || hh <= 2 * kBorder) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "image too small for the pyramid");
+        }
+        const double ratio = static_cast<double>(w - 2 * kBorder) / (hh - 2 * kBorder);
+        const int n0 = ratio > 1 ? static_cast<int>(std::round(ratio)) : static_cast<int>(std::round(1 / ratio));
+        total += std::max(2 * static_cast<int>(h->num_keypts_per_level.at(l)), 4 * n0) + 8;
+    }
+    return total;
+}
+
+int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, int width, int height,
+                              size_t row_stride, size_t frame_stride,
+                              const uint8_t* d_mask, size_t mask_stride,
+                              ovs_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap,
+                              void* stream_) {
+    if (!h) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null handle");
+    }
+    if (!d_imgs || width <= 0 || height <= 0 || n_frames <= 0) {
+        return OVS_OK; // empty image: outputs untouched (orb_extractor.cc:70-72)
+    }
+    if (!d_kps || !d_desc || !d_counts || cap <= 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null output buffer");
+    }
+    if (row_stride < static_cast<size_t>(width)) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "row stride smaller than the width");
+    }
+    ovs::device_guard guard(h->device);
+    if (!guard.ok) {
+        return ovs::fail(OVS_ERR_HIP, "cannot select the handle's device");
+    }
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int rc;
+    if ((rc = build_plan(h, width, height)) != OVS_OK) return rc;
+    if ((rc = ensure_buffers(h, n_frames)) != OVS_OK) return rc;
+    if ((rc = upload_constants(h)) != OVS_OK) return rc;
+    if ((rc = ensure_rect_mask(h, width, height)) != OVS_OK) return rc;
+    const plan_dev& p = h->plan;
+
+    image_src src;
+    src.img0 = d_imgs;
+    src.row_stride0 = static_cast<long long>(row_stride);
+    src.frame_stride0 = static_cast<long long>(frame_stride);
+    src.pyr = h->pyr.as<uint8_t>();
+    src.mask = nullptr;
+    src.mask_stride = 0;
+    src.mask_w = width;
+    src.mask_h = height;
+    if (d_mask) {
+        src.mask = d_mask;
+        src.mask_stride = static_cast<long long>(mask_stride);
+    }
+    else if (h->mask_is_initialized) {
+        // the rectangle mask keeps the size of the first image it was created for
+        src.mask = h->rect_mask.as<uint8_t>();
+        src.mask_stride = h->rect_mask_w;
+        src.mask_w = h->rect_mask_w;
+        src.mask_h = h->rect_mask_h;
+    }
+
+    for (int l = 1; l < p.num_levels; ++l) {
+        const level_geom& g = p.lv[l];
+        dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, n_frames), block(64, 4, 1);
+        OVS_LAUNCH("k_resize_linear", k_resize_linear, grid, block, 0, stream, p, src, h->tabs.as<int>(), l);
+    }
+    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(p.total_cells, n_frames), dim3(256), 0, stream,
+               p, src, h->slots.as<u32>(), h->cell_counts.as<u32>());
+    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(p.total_blur_tiles, n_frames), dim3(256), 0, stream,
+               p, src, h->blur.as<uint8_t>());
+    OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
+               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand_xy.as<u32>(), h->cand_st.as<u32>(),
+               h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
+    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3((p.kp_total_cap + 3) / 4, n_frames), dim3(256), 0, stream,
+               p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
+               d_kps, d_desc, d_counts, cap);
+    OVS_HIP(hipGetLastError());
+
+    h->last_img0 = d_imgs;
+    h->last_row_stride0 = src.row_stride0;
+    h->last_frame_stride0 = src.frame_stride0;
+    h->last_frames = n_frames;
+    return OVS_OK;
+}
+
+int ovs_orb_extract(ovs_orb* h, const uint8_t* img, int width, int height, size_t stride,
+                    const uint8_t* mask, size_t mask_stride,
+                    ovs_keypoint* kps, uint8_t* desc, int cap, int* n) {
+    if (!h) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null handle");
+    }
+    if (!img || width <= 0 || height <= 0) {
+        return OVS_OK; // empty image: outputs untouched
+    }
+    if (!kps || !desc || !n || cap <= 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null output buffer");
+    }
+    ovs::device_guard guard(h->device);
+    if (!guard.ok) {
+        return ovs::fail(OVS_ERR_HIP, "cannot select the handle's device");
+    }
+    int rc;
+    if (!h->own_stream) {
+        OVS_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    }
+    const int dcap = ovs_orb_keypoint_capacity(h, width, height);
+    if (dcap < 0) {
+        return dcap;
+    }
+    const size_t pitch = (static_cast<size_t>(width) + 63) & ~static_cast<size_t>(63);
+    if ((rc = h->st_img.reserve(pitch * height)) != OVS_OK) return rc;
+    if ((rc = h->st_kps.reserve(static_cast<size_t>(dcap) * sizeof(ovs_keypoint))) != OVS_OK) return rc;
+    if ((rc = h->st_desc.reserve(static_cast<size_t>(dcap) * 32)) != OVS_OK) return rc;
+    if ((rc = h->st_count.reserve(sizeof(int))) != OVS_OK) return rc;
+    OVS_HIP(hipMemcpy2DAsync(h->st_img.ptr, pitch, img, stride, width, height, hipMemcpyHostToDevice, h->own_stream));
+    const uint8_t* d_mask = nullptr;
+    if (mask) {
+        if ((rc = h->st_mask.reserve(pitch * height)) != OVS_OK) return rc;
+        OVS_HIP(hipMemcpy2DAsync(h->st_mask.ptr, pitch, mask, mask_stride, width, height, hipMemcpyHostToDevice, h->own_stream));
+        d_mask = h->st_mask.as<uint8_t>();
+    }
+    rc = ovs_orb_extract_batch_dev(h, h->st_img.as<uint8_t>(), 1, width, height, pitch, pitch * height,
+                                   d_mask, pitch, h->st_kps.as<ovs_keypoint>(), h->st_desc.as<uint8_t>(),
+                                   h->st_count.as<int32_t>(), dcap, h->own_stream);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    int count = 0;
+    OVS_HIP(hipMemcpyAsync(&count, h->st_count.ptr, sizeof(int), hipMemcpyDeviceToHost, h->own_stream));
+    OVS_HIP(hipStreamSynchronize(h->own_stream));
+    if (count < 0) {
+        return ovs::fail(OVS_ERR_CAPACITY, "internal keypoint capacity exceeded");
+    }
+    *n = count;
+    if (count > cap) {
+        return ovs::fail(OVS_ERR_CAPACITY, "keypoint buffer too small");
+    }
+    if (count > 0) {
+        OVS_HIP(hipMemcpy(kps, h->st_kps.ptr, static_cast<size_t>(count) * sizeof(ovs_keypoint), hipMemcpyDeviceToHost));
+        OVS_HIP(hipMemcpy(desc, h->st_desc.ptr, static_cast<size_t>(count) * 32, hipMemcpyDeviceToHost));
+    }
+    return OVS_OK;
+}
+
+int ovs_orb_pyramid_level_dev(ovs_orb* h, int frame, int level,
+                              const uint8_t** d_ptr, int* width, int* height, size_t* stride) {
+    if (!h || h->last_frames == 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "no extraction has run on this handle");
+    }
+    if (frame < 0 || frame >= h->last_frames || level < 0 || level >= h->plan.num_levels) {
+        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "frame or level out of range");
+    }
+    const level_geom& g = h->plan.lv[level];
+    *width = g.w;
+    *height = g.h;
+    if (level == 0) {
+        *d_ptr = h->last_img0 + frame * h->last_frame_stride0;
+        *stride = static_cast<size_t>(h->last_row_stride0);
+    }
+    else {
+        *d_ptr = h->pyr.as<uint8_t>() + frame * h->plan.frame_pyr_bytes + g.pyr_off;
+        *stride = static_cast<size_t>(g.pitch);
+    }
+    return OVS_OK;
+}
+
+int ovs_orb_download_pyramid_level(ovs_orb* h, int frame, int level, uint8_t* out, size_t out_stride) {
+    const uint8_t* d = nullptr;
+    int w = 0, hh = 0;
+    size_t stride = 0;
+    int rc = ovs_orb_pyramid_level_dev(h, frame, level, &d, &w, &hh, &stride);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(h->device);
+    OVS_HIP(hipDeviceSynchronize());
+    OVS_HIP(hipMemcpy2D(out, out_stride, d, stride, w, hh, hipMemcpyDeviceToHost));
+    return OVS_OK;
+}
+
+int ovs_orb_download_blurred_level(ovs_orb* h, int frame, int level, uint8_t* out, size_t out_stride) {
+    if (!h || h->last_frames == 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "no extraction has run on this handle");
+    }
+    if (frame < 0 || frame >= h->last_frames || level < 0 || level >= h->plan.num_levels) {
+        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "frame or level out of range");
+    }
+    const level_geom& g = h->plan.lv[level];
+    ovs::device_guard guard(h->device);
+    OVS_HIP(hipDeviceSynchronize());
+    OVS_HIP(hipMemcpy2D(out, out_stride, h->blur.as<uint8_t>() + frame * h->plan.frame_blur_bytes + g.blur_off, g.pitch,
+                        g.w, g.h, hipMemcpyDeviceToHost));
+    return OVS_OK;
+}
+
+} // extern "C"

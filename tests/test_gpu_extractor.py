@@ -1,0 +1,120 @@
+"""GPU parity of the ORB extractor against the CPU oracle, through the C ABI.
+
+Bit-exact bar: pyramid pixels, blurred pixels, keypoints (x, y, size, angle, response, octave) and
+descriptors must be identical to the oracle's on the same inputs.  (The north-star tolerance of
+99.9 % descriptor bits is for float angle rounding; oracle and device evaluate the same fp32
+operation sequence, so the tests require 100 %.)
+"""
+import numpy as np
+import pytest
+
+import oracle
+from openvslam_amd import synth
+from openvslam_amd.feature import orb_extractor, orb_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(img, mask=None, **params):
+    ref = oracle.OrbExtractor(**params)
+    rk, rd = ref.extract(img, mask)
+    ext = orb_extractor(orb_params(**params))
+    gk, gd = ext.extract(img, mask)
+    levels = params.get("num_levels", 8)
+    for lvl in range(1, levels):
+        assert np.array_equal(ext.image_pyramid(lvl), ref.pyramid_level(lvl)), "pyramid level %d differs" % lvl
+    for lvl in range(levels):
+        rb = ref.blurred_level(lvl)
+        if rb is not None:
+            assert np.array_equal(ext.blurred_level(lvl), rb), "blurred level %d differs" % lvl
+    assert len(gk) == len(rk), "keypoint count %d vs %d" % (len(gk), len(rk))
+    for field in ("octave", "x", "y", "response", "size", "class_id"):
+        assert np.array_equal(gk[field], rk[field]), "keypoint field %s differs" % field
+    assert np.array_equal(gk["angle"].view(np.uint32), rk["angle"].view(np.uint32)), "angles differ"
+    assert np.array_equal(gd, rd), "descriptors differ"
+    return gk, gd
+
+
+@pytest.mark.parametrize("w,h,n", [(640, 480, 1000), (1241, 376, 2000), (752, 480, 1000)])
+def test_extract_matches_oracle(w, h, n):
+    img = synth.make_frame(w, h, seed=1234 + w)
+    gk, _ = _compare(img, max_num_keypts=n)
+    assert len(gk) >= n // 2
+
+
+def test_extract_low_texture_uses_min_threshold():
+    # faint texture: most cells are empty at the initial threshold and fall back to the minimum one
+    rng = np.random.default_rng(7)
+    img = np.clip(128 + rng.normal(0, 3.5, (480, 640)), 0, 255).astype(np.uint8)
+    img[200:280, 300:420] += 30
+    _compare(img, max_num_keypts=1000)
+
+
+def test_extract_flat_image_has_no_keypoints():
+    img = np.full((480, 640), 77, dtype=np.uint8)
+    gk, gd = _compare(img, max_num_keypts=500)
+    assert len(gk) == 0 and gd.shape == (0, 32)
+
+
+def test_extract_toy_samples():
+    # test/openvslam/feature/orb_extractor.cc:24-76
+    img = np.full((600, 600), 255, dtype=np.uint8)
+    img[300:, 300:] = 0
+    gk, _ = _compare(img)
+    sf = orb_params.calc_scale_factors(8, 1.2)
+    assert len(gk) > 0
+    assert np.all(np.abs(gk["x"] - 300) <= 2.0 * sf[gk["octave"]])
+    assert np.all(np.abs(gk["y"] - 300) <= 2.0 * sf[gk["octave"]])
+    img = np.full((2000, 2000), 255, dtype=np.uint8)
+    img[:1801, :1801] = 0
+    gk, _ = _compare(img)
+    assert len(gk) > 0
+    assert np.all(np.abs(gk["x"] - 1800) <= 2.0 * sf[gk["octave"]])
+    assert np.all(np.abs(gk["y"] - 1800) <= 2.0 * sf[gk["octave"]])
+
+
+def test_extract_with_image_mask():
+    # test/openvslam/feature/orb_extractor.cc:116-141: top and bottom quarter masked
+    img = synth.make_frame(960, 480, seed=99)
+    mask = np.ones_like(img)
+    mask[:img.shape[0] // 4] = 0
+    mask[3 * img.shape[0] // 4:img.shape[0] - 1] = 0
+    gk, _ = _compare(img, mask)
+    assert len(gk) > 0
+    assert np.all(gk["y"] >= img.shape[0] // 4) and np.all(gk["y"] <= 3 * img.shape[0] // 4)
+
+
+def test_extract_with_rectangle_masks():
+    # the mask rectangles of the equirectangular tutorial configuration
+    rects = [[0.0, 1.0, 0.0, 0.1], [0.0, 1.0, 0.84, 1.0], [0.0, 0.2, 0.7, 1.0], [0.8, 1.0, 0.7, 1.0]]
+    img = synth.make_frame(960, 480, seed=5)
+    gk, _ = _compare(img, mask_rects=rects)
+    assert len(gk) > 0
+    h, w = img.shape
+    for x0, x1, y0, y1 in rects:
+        inside = (gk["x"] >= x0 * w) & (gk["x"] <= x1 * w) & (gk["y"] >= y0 * h) & (gk["y"] <= y1 * h)
+        assert not inside.any()
+
+
+def test_extract_other_parameters():
+    img = synth.make_frame(800, 600, seed=321)
+    _compare(img, max_num_keypts=300, scale_factor=1.5, num_levels=4, ini_fast_thr=30, min_fast_thr=10)
+    _compare(img, max_num_keypts=700, scale_factor=2.0, num_levels=3)
+    _compare(img, max_num_keypts=100, num_levels=1)
+
+
+def test_extract_portrait():
+    img = synth.make_frame(376, 900, seed=8)
+    _compare(img, max_num_keypts=1500)
+
+
+def test_empty_image_leaves_outputs_untouched():
+    ext = orb_extractor(orb_params())
+    assert ext.extract(np.zeros((0, 0), dtype=np.uint8)) == (None, None)
+
+
+def test_too_small_image_is_rejected():
+    from openvslam_amd._lib import OvsError
+    ext = orb_extractor(orb_params())
+    with pytest.raises(OvsError):
+        ext.extract(np.zeros((100, 100), dtype=np.uint8))
