@@ -1165,6 +1165,73 @@ int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, 
     return OVS_OK;
 }
 
+} // extern "C"
+
+namespace {
+
+// Fills the problem descriptors of a batch of consecutive-frame matches from device-side counts and
+// splits the query fields out of the previous frame's keypoints.  grid = (ceil(cap / 256), n_frames).
+__global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                     const int* __restrict__ counts, int n_frames, int cap,
+                                                     const float* __restrict__ reproj_xy, ovs_grid grid,
+                                                     const float* __restrict__ scale_factors, int num_levels,
+                                                     u32* cell_start, u32* cell_items, int ncell,
+                                                     int* sl, float* ang, uint8_t* valid, u64* lists, u32* totals, int* acc,
+                                                     int* matched, u32* num_matches, int* err, proj_problem* problems) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (f == 0) {
+        if (i < cap) {
+            matched[i] = -1;
+        }
+        if (i == 0) {
+            num_matches[0] = 0;
+        }
+        return;
+    }
+    const int n_last = max(min(counts[f - 1], cap), 0);
+    const size_t qo = (size_t)f * cap;
+    if (i < cap) {
+        const ovs_keypoint kp = kps[(size_t)(f - 1) * cap + min(i, max(n_last - 1, 0))];
+        sl[qo + i] = kp.octave;
+        ang[qo + i] = kp.angle;
+        valid[qo + i] = (i < n_last && !(reproj_xy[2 * (qo + i)] < -1e30f)) ? 1 : 0;
+        acc[qo + i] = -1;
+    }
+    if (i == 0) {
+        proj_problem P;
+        P.frm.n = max(min(counts[f], cap), 0);
+        P.frm.kps = kps + qo;
+        P.frm.desc = desc + qo * 32;
+        P.frm.sxr = nullptr;
+        P.frm.scale_factors = scale_factors;
+        P.frm.num_levels = num_levels;
+        P.frm.grid = grid;
+        P.frm.cell_start = cell_start + (size_t)f * (ncell + 1);
+        P.frm.cell_items = cell_items + qo;
+        P.q.n = n_last;
+        P.q.reproj_xy = reproj_xy + 2 * qo;
+        P.q.x_right = nullptr;
+        P.q.scale_level = sl + qo;
+        P.q.angle = ang + qo;
+        P.q.desc = desc + (size_t)(f - 1) * cap * 32;
+        P.q.valid = valid + qo;
+        P.q.has_obs = nullptr;
+        P.occupied = nullptr;
+        P.lists = lists + qo * kTopK;
+        P.totals = totals + qo;
+        P.matched = matched + qo;
+        P.num_matches = num_matches + f;
+        P.acc_idx = acc + qo;
+        P.err = err;
+        problems[f - 1] = P;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
 int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_t* d_desc,
                                          const int32_t* d_counts, int n_frames, int cap,
                                          const float* d_reproj_xy, const ovs_grid* grid,
@@ -1172,7 +1239,57 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
                                          float margin, int check_orientation,
                                          int32_t* d_matched, uint32_t* d_num_matches,
                                          int device, void* stream_) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
+    if (!d_kps || !d_desc || !d_counts || !d_reproj_xy || !grid || !scale_factors || !d_matched || !d_num_matches
+        || n_frames <= 0 || cap <= 0 || num_scale_levels <= 0 || num_scale_levels > 64) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if (cap >= (1 << 20)) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 2^20 keypoints per frame are not supported");
+    }
+    const size_t ncell = static_cast<size_t>(grid->num_cols) * grid->num_rows;
+    if (ncell == 0 || ncell > 16384) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "grids with more than 16384 cells are not supported");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const size_t F = n_frames, fc = F * cap;
+    const size_t total = al(64 * 4) + al(F * (ncell + 1) * 4) + al(fc * 4) * 5 + al(fc) + al(fc * kTopK * 8) + al(256) + al(F * sizeof(proj_problem));
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    auto* d_sf = cv.take<float>(64);
+    auto* d_cell_start = cv.take<u32>(F * (ncell + 1));
+    auto* d_cell_items = cv.take<u32>(fc);
+    auto* d_sl = cv.take<int>(fc);
+    auto* d_ang = cv.take<float>(fc);
+    auto* d_totals = cv.take<u32>(fc);
+    auto* d_acc = cv.take<int>(fc);
+    auto* d_valid = cv.take<uint8_t>(fc);
+    auto* d_lists = cv.take<u64>(fc * kTopK);
+    auto* d_err = cv.take<int>(1);
+    auto* d_prob = cv.take<proj_problem>(F);
+    OVS_HIP(hipMemcpyAsync(d_sf, scale_factors, static_cast<size_t>(num_scale_levels) * 4, hipMemcpyHostToDevice, st));
+
+    proj_params pp{kCurrLast, margin, OVS_DIR_NONE, num_scale_levels, 0.0f, kThrHigh, check_orientation};
+    OVS_LAUNCH("k_batch_setup", k_batch_setup, dim3((cap + 255) / 256, n_frames), dim3(256), 0, st,
+               d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, num_scale_levels,
+               d_cell_start, d_cell_items, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,
+               d_matched, d_num_matches, d_err, d_prob);
+    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
+               d_kps, d_counts, 0, cap, *grid, d_cell_start, d_cell_items);
+    if (n_frames > 1) {
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((cap + 3) / 4, n_frames - 1), dim3(256), 0, st, d_prob, pp);
+        OVS_LAUNCH("k_proj_resolve", k_proj_resolve, dim3(n_frames - 1), dim3(64), ((cap + 31) / 32 + 1) * 4, st, d_prob, pp);
+    }
+    OVS_HIP(hipGetLastError());
+    return OVS_OK;
 }
 
 // ---- descriptor database ---------------------------------------------------------------------------

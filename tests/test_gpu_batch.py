@@ -1,0 +1,71 @@
+"""GPU parity of the batched device-pointer path (extract batch + consecutive-frame matching),
+the path bench.py times, against the oracle run frame by frame."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from openvslam_amd import _abi as A
+from openvslam_amd import _lib, synth
+from openvslam_amd.feature import orb_extractor, orb_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("w,h,n_kp,n_frames", [(640, 480, 1000, 5), (1241, 376, 2000, 4)])
+def test_batch_extract_and_match(w, h, n_kp, n_frames):
+    dev = torch.device("cuda", 0)
+    dx, dy = 3, 1
+    frames = synth.make_sequence(w, h, n_frames, seed=77, dx=dx, dy=dy)
+    d_frames = torch.from_numpy(frames).to(dev)
+    ext = orb_extractor(orb_params(max_num_keypts=n_kp), device=0)
+    cap = ext.keypoint_capacity(w, h)
+    kps = torch.zeros((n_frames, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_frames, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ext.extract_batch_dev(d_frames.data_ptr(), n_frames, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+    reproj = torch.full((n_frames, cap, 2), -1e38, dtype=torch.float32, device=dev)
+    reproj[1:] = kps[:-1, :, 0:2] - torch.tensor([float(dx), float(dy)], device=dev)
+    matched = torch.zeros((n_frames, cap), dtype=torch.int32, device=dev)
+    num = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    grid = A.make_grid(0.0, 0.0, float(w), float(h))
+    sf = ext.get_scale_factors()
+    _lib.check(_lib.lib().ovs_match_batch_current_and_last_dev(
+        kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), n_frames, cap, reproj.data_ptr(), C.byref(grid),
+        A.ptr(sf, A.f32p), 8, 20.0, 1, matched.data_ptr(), num.data_ptr(), 0, stream))
+    torch.cuda.synchronize(dev)
+
+    h_counts = counts.cpu().numpy()
+    h_kps = kps.cpu().numpy().view(np.uint8).reshape(n_frames, cap, 28).copy().view(A.KEYPOINT_DTYPE).reshape(n_frames, cap)
+    h_desc = desc.cpu().numpy()
+    h_matched = matched.cpu().numpy()
+    h_num = num.cpu().numpy()
+
+    ref = oracle.OrbExtractor(max_num_keypts=n_kp)
+    r_kps = np.zeros((n_frames, cap), dtype=A.KEYPOINT_DTYPE)
+    r_desc = np.zeros((n_frames, cap, 32), dtype=np.uint8)
+    r_counts = np.zeros(n_frames, dtype=np.int32)
+    for f in range(n_frames):
+        k, d = ref.extract(frames[f])
+        r_counts[f] = len(k)
+        r_kps[f, :len(k)] = k
+        r_desc[f, :len(k)] = d
+        assert h_counts[f] == len(k)
+        assert np.array_equal(h_kps[f, :len(k)].view(np.uint8), k.view(np.uint8)), "frame %d keypoints differ" % f
+        assert np.array_equal(h_desc[f, :len(k)], d), "frame %d descriptors differ" % f
+    r_reproj = np.full((n_frames, cap, 2), -1e38, dtype=np.float32)
+    r_reproj[1:, :, 0] = r_kps["x"][:-1] - np.float32(dx)
+    r_reproj[1:, :, 1] = r_kps["y"][:-1] - np.float32(dy)
+    r_matched = np.zeros((n_frames, cap), dtype=np.int32)
+    r_num = np.zeros(n_frames, dtype=np.uint32)
+    oracle.check(oracle.lib().ovo_match_batch_current_and_last(
+        A.ptr(r_kps, A.kpp), A.ptr(r_desc, A.u8p), A.ptr(r_counts, A.i32p), n_frames, cap, A.ptr(r_reproj, A.f32p),
+        C.byref(grid), A.ptr(sf, A.f32p), 8, 20.0, 1, A.ptr(r_matched, A.i32p), A.ptr(r_num, A.u32p)))
+    assert np.array_equal(h_num.astype(np.uint32), r_num)
+    for f in range(n_frames):
+        n = r_counts[f]
+        assert np.array_equal(h_matched[f, :n], r_matched[f, :n]), "frame %d matches differ" % f
+    assert r_num[1:].min() > n_kp // 10
