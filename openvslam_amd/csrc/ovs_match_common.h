@@ -1,0 +1,154 @@
+// ovs_match_common.h -- device helpers (popcount Hamming, wave reductions) and host plumbing
+// (per-thread stream + scratch arena) shared by the matcher translation units.
+#ifndef OVS_MATCH_COMMON_H
+#define OVS_MATCH_COMMON_H
+
+#include "ovs_internal.h"
+
+#include <vector>
+
+namespace ovsm {
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+
+constexpr u32 kThrLow = 50;   // HAMMING_DIST_THR_LOW, src/openvslam/match/base.h:13
+constexpr u32 kThrHigh = 100; // HAMMING_DIST_THR_HIGH, src/openvslam/match/base.h:14
+constexpr u32 kMaxDist = 256; // MAX_HAMMING_DIST, src/openvslam/match/base.h:15
+constexpr u64 kNoKey = ~0ull;
+
+// compute_descriptor_distance_32 (src/openvslam/match/base.h:18-39): the SWAR bit count of the
+// reference is v_bcnt_u32_b32 here, 8 dwords per descriptor.
+__device__ __forceinline__ u32 hamming8(const u32* a, const u32* b) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        d += __popc(a[i] ^ b[i]);
+    }
+    return d;
+}
+
+__device__ __forceinline__ void load_desc(const uint8_t* p, u32* out) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(p);
+    const uint4 hi = *reinterpret_cast<const uint4*>(p + 16);
+    out[0] = lo.x; out[1] = lo.y; out[2] = lo.z; out[3] = lo.w;
+    out[4] = hi.x; out[5] = hi.y; out[6] = hi.z; out[7] = hi.w;
+}
+
+// descriptors that are only 4-byte aligned (caller buffers)
+__device__ __forceinline__ void load_desc4(const uint8_t* p, u32* out) {
+    const u32* q = reinterpret_cast<const u32*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        out[i] = q[i];
+    }
+}
+
+template <int W>
+__device__ __forceinline__ u64 group_min_u64(u64 v) {
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+        const u32 lo = __shfl_xor((u32)v, d, W);
+        const u32 hi = __shfl_xor((u32)(v >> 32), d, W);
+        const u64 o = ((u64)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+template <int W>
+__device__ __forceinline__ u32 group_sum_u32(u32 v) {
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+        v += __shfl_xor(v, d, W);
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) { return group_sum_u32<64>(v); }
+__device__ __forceinline__ u64 wave_min_u64(u64 v) { return group_min_u64<64>(v); }
+
+__device__ __forceinline__ int cv_floor_dd(double v) {
+    const int i = (int)v;
+    return i - (i > v);
+}
+__device__ __forceinline__ int cv_ceil_dd(double v) {
+    const int i = (int)v;
+    return i + (i < v);
+}
+__device__ __forceinline__ int cv_floor_ff(float v) {
+    const int i = (int)v;
+    return i - (i > v);
+}
+__device__ __forceinline__ int cv_ceil_ff(float v) {
+    const int i = (int)v;
+    return i + (i < v);
+}
+
+// angle_checker::append_delta_angle, src/openvslam/match/angle_checker.h:72-83 (30 bins)
+__device__ __forceinline__ int angle_bin(float delta_angle) {
+    if (delta_angle < 0.0f) {
+        delta_angle = __fadd_rn(delta_angle, 360.0f);
+    }
+    if (360.0f <= delta_angle) {
+        delta_angle = __fsub_rn(delta_angle, 360.0f);
+    }
+    return __float2int_rn(__fmul_rn(delta_angle, 1.0f / 30));
+}
+
+// ---- host plumbing ----------------------------------------------------------------------------------
+// One stream and one growable scratch arena per (host thread, device): the matcher entry points
+// keep no other state, so they can be called from the tracking, mapping and global optimisation
+// threads concurrently.
+struct thread_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    ovs::dev_buffer arena;
+};
+
+inline thread_ctx* ctx_for(int device) {
+    static thread_local std::vector<thread_ctx> ctxs;
+    for (auto& c : ctxs) {
+        if (c.device == device) {
+            return &c;
+        }
+    }
+    ctxs.emplace_back();
+    ctxs.back().device = device;
+    return &ctxs.back();
+}
+
+struct carver {
+    uint8_t* base = nullptr;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += (n * sizeof(T) + 255) & ~static_cast<size_t>(255);
+        return p;
+    }
+};
+
+inline size_t al(size_t bytes) { return (bytes + 255) & ~static_cast<size_t>(255); }
+
+inline int check_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        return ovs::fail(OVS_ERR_HIP, "no HIP device available (this library has no CPU path)");
+    }
+    if (device < 0 || device >= ndev) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    }
+    return OVS_OK;
+}
+
+inline int ensure_stream(thread_ctx* c) {
+    if (!c->stream) {
+        OVS_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
+    return OVS_OK;
+}
+
+} // namespace ovsm
+
+#endif

@@ -1,0 +1,1279 @@
+// ovs_projection.hip -- match::projection (src/openvslam/match/projection.cc) and the camera-grid
+// window query it is built on (src/openvslam/data/common.cc:97-186) for gfx950.
+//
+// Kernels
+//   k_grid_build       one workgroup per searched frame: counting sort of its keypoints into the
+//                      camera grid.  Cells are flattened x-major (cell = cx * rows + cy) and keypoint
+//                      indices ascend inside a cell, so the candidates of a window
+//                      [min_cx..max_cx] x [min_cy..max_cy] are, per column cx, ONE contiguous range
+//                      of the sorted arrays, visited in exactly the order of the nested loops of
+//                      get_keypoints_in_cell (common.cc:156-181).  The sort also writes position,
+//                      octave, index and descriptor of every keypoint in grid order, so a window
+//                      scan reads contiguous memory.
+//   k_proj_candidates  16 lanes per query: prefix over the window's column ranges, lanes stride over
+//                      the concatenated ranges, gates that do not depend on earlier queries, popcount
+//                      Hamming, and the K smallest (distance, scan position) keys per query.
+//   k_proj_resolve     one wavefront per matching problem: reproduces the loop-carried dependency
+//                      `frm.landmarks_[best] = lm` (projection.cc:164,190) -- see the kernel comment --
+//                      and the rotation-histogram check (match/angle_checker.h).
+//   k_window_list      get_keypoints_in_cell itself (index lists in the reference's order).
+#include "ovs_match_common.h"
+#include "std_sort_port.h"
+
+#include <algorithm>
+#include <cstring>
+
+using namespace ovsm;
+
+namespace {
+
+constexpr int kTopK = 8;
+constexpr int kGroup = 16; // lanes per query in k_proj_candidates
+
+enum proj_kind {
+    kCurrLast = 0,    // projection::match_current_and_last_frames
+    kFrameLms = 1,    // projection::match_frame_and_landmarks
+    kFrameKeyfrm = 2, // projection::match_frame_and_keyframe
+    kSim3 = 3,        // projection::match_by_Sim3_transform
+    kOneWay = 4       // one direction of projection::match_keyframes_mutually
+};
+
+struct frame_dev {
+    int n;
+    const ovs_keypoint* kps;
+    const uint8_t* desc;
+    const float* sxr; // stereo_x_right or nullptr
+    const float* scale_factors;
+    int num_levels;
+    ovs_grid grid;
+    const u32* cell_start; // num_cols * num_rows + 1
+    const uint4* g_entry;  // grid order: {x bits, y bits, octave, keypoint index}
+    const uint4* g_desc;   // grid order: two uint4 per keypoint
+};
+
+struct query_dev {
+    int n;
+    const float* reproj_xy;
+    const float* x_right;
+    const int* scale_level;
+    const float* angle;
+    const uint8_t* desc;
+    const uint8_t* valid;
+    const uint8_t* has_obs;
+};
+
+struct proj_params {
+    int kind;
+    float margin;
+    int direction;
+    int last_levels;
+    float lowe;
+    u32 thr;
+    int check_orientation;
+};
+
+struct proj_problem {
+    frame_dev frm;
+    query_dev q;
+    const uint8_t* occupied; // static occupancy of the searched frame or nullptr
+    u64* lists;              // q.n * kTopK
+    u32* totals;             // q.n
+    int* matched;            // frm.n
+    u32* num_matches;
+    int* acc_idx;            // q.n  accepted keypoint index or -1
+    int* err;
+};
+
+// ---- grid ---------------------------------------------------------------------------------------
+// data::get_cell_indices, src/openvslam/data/common.h:59-64
+__device__ __forceinline__ bool cell_of(const ovs_grid& g, float x, float y, int& cx, int& cy) {
+    cx = cv_floor_dd((double)(x - g.min_x) * g.inv_cell_width);
+    cy = cv_floor_dd((double)(y - g.min_y) * g.inv_cell_height);
+    return 0 <= cx && cx < (int)g.num_cols && 0 <= cy && cy < (int)g.num_rows;
+}
+
+__global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+                                                    const int* __restrict__ counts, int fixed_n, int cap, ovs_grid g,
+                                                    u32* __restrict__ cell_start_all, u32* __restrict__ items_all,
+                                                    uint4* __restrict__ entry_all, uint4* __restrict__ gdesc_all) {
+    extern __shared__ u32 sm[];
+    __shared__ u32 red[8];
+    const int f = blockIdx.x;
+    const int n = counts ? max(min(counts[f], cap), 0) : fixed_n;
+    const int ncell = (int)(g.num_cols * g.num_rows);
+    const ovs_keypoint* kps = kps_all + (size_t)f * cap;
+    const uint8_t* desc = desc_all + (size_t)f * cap * 32;
+    u32* cell_start = cell_start_all + (size_t)f * (ncell + 1);
+    u32* items = items_all + (size_t)f * cap;
+    uint4* entry = entry_all + (size_t)f * cap;
+    uint4* gdesc = gdesc_all + (size_t)f * cap * 2;
+    u32* cnt = sm;             // ncell + 1
+    u32* cur = sm + ncell + 1; // ncell
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (int c = tid; c <= ncell; c += 256) {
+        cnt[c] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int cx, cy;
+        if (cell_of(g, kps[i].x, kps[i].y, cx, cy)) {
+            atomicAdd(&cnt[cx * g.num_rows + cy], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const int per = (ncell + 1 + 255) / 256;
+        const int b = min(tid * per, ncell + 1), e = min(b + per, ncell + 1);
+        u32 sum = 0;
+        for (int i = b; i < e; ++i) {
+            sum += cnt[i];
+        }
+        u32 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(inc, d);
+            if (lane >= d) {
+                inc += t;
+            }
+        }
+        if (lane == 63) {
+            red[wave] = inc;
+        }
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; ++w) {
+            woff += red[w];
+        }
+        u32 run = woff + inc - sum;
+        for (int i = b; i < e; ++i) {
+            const u32 v = cnt[i];
+            cnt[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c <= ncell; c += 256) {
+        cell_start[c] = cnt[c];
+        if (c < ncell) {
+            cur[c] = cnt[c];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int cx, cy;
+        if (cell_of(g, kps[i].x, kps[i].y, cx, cy)) {
+            const u32 pos = atomicAdd(&cur[cx * g.num_rows + cy], 1u);
+            items[pos] = (u32)i;
+        }
+    }
+    __syncthreads();
+    // insertion order inside a cell is ascending keypoint index (common.cc:111-116)
+    for (int c = tid; c < ncell; c += 256) {
+        const u32 b = cnt[c], e = cnt[c + 1];
+        for (u32 i = b + 1; i < e; ++i) {
+            const u32 v = items[i];
+            u32 j = i;
+            while (j > b && items[j - 1] > v) {
+                items[j] = items[j - 1];
+                --j;
+            }
+            items[j] = v;
+        }
+    }
+    __syncthreads();
+    const int total = (int)cnt[ncell];
+    for (int j = tid; j < total; j += 256) {
+        const u32 i = items[j];
+        const ovs_keypoint kp = kps[i];
+        entry[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), (u32)kp.octave, i);
+        const u32* d = reinterpret_cast<const u32*>(desc + 32 * (size_t)i);
+        gdesc[2 * j] = make_uint4(d[0], d[1], d[2], d[3]);
+        gdesc[2 * j + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+    }
+}
+
+// ---- window scan --------------------------------------------------------------------------------
+struct window {
+    int min_cx, max_cx, min_cy, max_cy;
+    bool empty;
+};
+
+// the cell range of data::get_keypoints_in_cell, src/openvslam/data/common.cc:134-152
+__device__ __forceinline__ window window_of(const ovs_grid& g, float ref_x, float ref_y, float margin) {
+    window w;
+    w.empty = true;
+    w.min_cx = w.max_cx = w.min_cy = w.max_cy = 0;
+    w.min_cx = max(0, cv_floor_dd((double)(ref_x - g.min_x - margin) * g.inv_cell_width));
+    if ((int)g.num_cols <= w.min_cx) {
+        return w;
+    }
+    w.max_cx = min((int)g.num_cols - 1, cv_ceil_dd((double)(ref_x - g.min_x + margin) * g.inv_cell_width));
+    if (w.max_cx < 0) {
+        return w;
+    }
+    w.min_cy = max(0, cv_floor_dd((double)(ref_y - g.min_y - margin) * g.inv_cell_height));
+    if ((int)g.num_rows <= w.min_cy) {
+        return w;
+    }
+    w.max_cy = min((int)g.num_rows - 1, cv_ceil_dd((double)(ref_y - g.min_y + margin) * g.inv_cell_height));
+    if (w.max_cy < 0) {
+        return w;
+    }
+    w.empty = w.max_cx < w.min_cx || w.max_cy < w.min_cy;
+    return w;
+}
+
+struct query_ctx {
+    float rx, ry, margin, xr;
+    int min_level, max_level; // gate of get_keypoints_in_cell
+    bool ugate;               // unsigned level gate of projection.cc:390,515,598
+    u32 sl;
+    bool stereo_gate;
+};
+
+__device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const frame_dev& f, const query_dev& q, int qi, query_ctx& c) {
+    const int sl = q.scale_level[qi];
+    if (sl < 0 || f.num_levels <= sl) {
+        return false;
+    }
+    c.rx = q.reproj_xy[2 * qi];
+    c.ry = q.reproj_xy[2 * qi + 1];
+    c.margin = __fmul_rn(pp.margin, f.scale_factors[sl]);
+    c.xr = q.x_right ? q.x_right[qi] : -1.0f;
+    c.sl = (u32)sl;
+    c.ugate = false;
+    c.stereo_gate = false;
+    switch (pp.kind) {
+        case kCurrLast:
+            if (pp.direction == OVS_DIR_FORWARD) {
+                c.min_level = sl;
+                c.max_level = pp.last_levels - 1;
+            }
+            else if (pp.direction == OVS_DIR_BACKWARD) {
+                c.min_level = 0;
+                c.max_level = sl;
+            }
+            else {
+                c.min_level = sl - 1;
+                c.max_level = sl + 1;
+            }
+            c.stereo_gate = true;
+            break;
+        case kFrameLms:
+            c.min_level = sl - 1;
+            c.max_level = sl;
+            c.stereo_gate = true;
+            break;
+        case kFrameKeyfrm:
+            c.min_level = sl - 1;
+            c.max_level = sl + 1;
+            break;
+        default:
+            c.min_level = -1;
+            c.max_level = -1;
+            c.ugate = true;
+            break;
+    }
+    return true;
+}
+
+// key = distance (9 bits) << 40 | scan position (20 bits) << 20 | keypoint index (20 bits)
+__device__ __forceinline__ u64 make_key(u32 dist, u32 pos, u32 idx) { return ((u64)dist << 40) | ((u64)pos << 20) | idx; }
+__device__ __forceinline__ u32 key_dist(u64 k) { return (u32)(k >> 40); }
+__device__ __forceinline__ u32 key_idx(u64 k) { return (u32)(k & 0xFFFFFu); }
+
+// window / level gates of get_keypoints_in_cell (common.cc:166-178) + the per-candidate gates of
+// the projection loops that do not depend on earlier queries
+__device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx& c, const uint4& en, const uint8_t* occupied, const u32* blocked,
+                                             bool matcher_gates) {
+    const int oct = (int)en.z;
+    const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
+    if (check_level) {
+        if (oct < c.min_level) {
+            return false;
+        }
+        if (0 <= c.max_level && c.max_level < oct) {
+            return false;
+        }
+    }
+    const float dist_x = __fsub_rn(__uint_as_float(en.x), c.rx);
+    const float dist_y = __fsub_rn(__uint_as_float(en.y), c.ry);
+    if (!(fabsf(dist_x) < c.margin && fabsf(dist_y) < c.margin)) {
+        return false;
+    }
+    if (!matcher_gates) {
+        return true;
+    }
+    const u32 idx = en.w;
+    if (occupied && occupied[idx]) {
+        return false;
+    }
+    if (blocked && ((blocked[idx >> 5] >> (idx & 31)) & 1u)) {
+        return false;
+    }
+    if (c.ugate) {
+        const u32 uo = (u32)oct;
+        if (uo < c.sl - 1u || c.sl < uo) {
+            return false;
+        }
+    }
+    if (c.stereo_gate && f.sxr) {
+        const float sx = f.sxr[idx];
+        if (sx > 0) {
+            const float err = fabsf(__fsub_rn(c.xr, sx));
+            if (c.margin < err) {
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// Scan of one query window by a group of G lanes that share the query.  Returns (in every lane of
+// the group) the K smallest keys among the keypoints that pass all gates; `total` counts them.
+template <int G, int K>
+__device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* qd, const uint8_t* occupied,
+                            const u32* blocked, u64 (&top)[K], u32& total) {
+    const int gl = threadIdx.x & (G - 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        top[k] = kNoKey;
+    }
+    total = 0;
+    const window w = window_of(f.grid, c.rx, c.ry, c.margin);
+    if (w.empty) {
+        return;
+    }
+    const int R = (int)f.grid.num_rows;
+    const int ncx = w.max_cx - w.min_cx + 1;
+    u64 loc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        loc[k] = kNoKey;
+    }
+    u32 cnt = 0, posbase = 0;
+    for (int cb = 0; cb < ncx; cb += G) {
+        u32 s = 0, e = 0;
+        if (cb + gl < ncx) {
+            const int cx = w.min_cx + cb + gl;
+            s = f.cell_start[cx * R + w.min_cy];
+            e = f.cell_start[cx * R + w.max_cy + 1];
+        }
+        const u32 len = e - s;
+        u32 inc = len;
+#pragma unroll
+        for (int d = 1; d < G; d <<= 1) {
+            const u32 t = __shfl_up(inc, d, G);
+            if (gl >= d) {
+                inc += t;
+            }
+        }
+        const u32 T = __shfl(inc, G - 1, G);
+        const u32 exc = inc - len;
+        for (u32 t0 = 0; t0 < T; t0 += G) {
+            const u32 t = t0 + gl;
+            int lo = 0; // first lane whose inclusive prefix exceeds t = the column holding candidate t
+#pragma unroll
+            for (int step = G / 2; step >= 1; step >>= 1) {
+                const u32 v = __shfl(inc, lo + step - 1, G);
+                if (t >= v) {
+                    lo += step;
+                }
+            }
+            const u32 cs = __shfl(s, lo, G), cexc = __shfl(exc, lo, G);
+            if (t < T) {
+                const u32 j = cs + (t - cexc);
+                const uint4 en = f.g_entry[j];
+                if (passes_gates(f, c, en, occupied, blocked, true)) {
+                    const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
+                    const u32 dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w)
+                                     + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                    u64 key = make_key(dist, posbase + t, en.w);
+                    ++cnt;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (key < loc[k]) {
+                            const u64 tmp = loc[k];
+                            loc[k] = key;
+                            key = tmp;
+                        }
+                    }
+                }
+            }
+        }
+        posbase += T;
+    }
+    total = group_sum_u32<G>(cnt);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const u64 m = group_min_u64<G>(loc[0]);
+        top[k] = m;
+        if (loc[0] == m && m != kNoKey) {
+#pragma unroll
+            for (int t = 0; t + 1 < K; ++t) {
+                loc[t] = loc[t + 1];
+            }
+            loc[K - 1] = kNoKey;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __restrict__ problems, proj_params pp) {
+    const proj_problem& P = problems[blockIdx.y];
+    constexpr int QPB = 256 / kGroup;
+    const int qi = blockIdx.x * QPB + (threadIdx.x / kGroup);
+    const int gl = threadIdx.x & (kGroup - 1);
+    if (qi >= P.q.n) {
+        return;
+    }
+    u64 top[kTopK];
+    u32 total = 0;
+#pragma unroll
+    for (int k = 0; k < kTopK; ++k) {
+        top[k] = kNoKey;
+    }
+    query_ctx c;
+    if (P.q.valid[qi]) {
+        if (make_query_ctx(pp, P.frm, P.q, qi, c)) {
+            u32 qd[8];
+            load_desc(P.q.desc + 32 * (size_t)qi, qd);
+            window_topk<kGroup, kTopK>(P.frm, c, qd, P.occupied, nullptr, top, total);
+        }
+        else if (gl == 0) {
+            *P.err = OVS_ERR_OUT_OF_RANGE;
+        }
+    }
+    if (gl < kTopK) {
+        u64 v = top[0];
+#pragma unroll
+        for (int k = 1; k < kTopK; ++k) {
+            v = gl == k ? top[k] : v;
+        }
+        P.lists[(size_t)qi * kTopK + gl] = v;
+    }
+    if (gl == 0) {
+        P.totals[qi] = total;
+    }
+}
+
+// ---- resolution ---------------------------------------------------------------------------------
+__device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_dev& f, u64 best, u64 second) {
+    const u32 bd = key_dist(best);
+    switch (pp.kind) {
+        case kFrameLms: {
+            if (bd > kThrHigh) {
+                return false;
+            }
+            // Lowe's ratio only between candidates of the same octave, projection.cc:69-73
+            const int bl = f.kps[key_idx(best)].octave;
+            const int slv = second == kNoKey ? -1 : f.kps[key_idx(second)].octave;
+            const u32 sd = second == kNoKey ? kMaxDist : key_dist(second);
+            return !(bl == slv && (float)bd > __fmul_rn(pp.lowe, (float)sd));
+        }
+        case kFrameKeyfrm:
+            return bd <= pp.thr;
+        case kSim3:
+            return bd <= kThrLow;
+        default:
+            return bd <= kThrHigh; // kCurrLast, kOneWay
+    }
+}
+
+// One wavefront per problem.
+//
+// The reference walks the queries in order; each takes the best candidate no earlier query has
+// claimed.  Here 64 consecutive queries are evaluated at once against the current claim bitmap;
+// every accepting lane posts its lane id on its pick with an LDS atomicMin, and a lane whose pick
+// (or, for the ratio test, whose runner-up) carries a smaller lane id has been overtaken by an
+// earlier query of the same round.  All lanes before the first overtaken one commit together, the
+// rest are re-evaluated in the next round, so the result is the serial one while a round usually
+// retires most of the chunk.  A query whose list ran dry while an unlisted candidate could still
+// change its outcome is handled alone with a full rescan of its window.
+// IN_LDS: the per-keypoint `matched` and `claim` arrays fit in LDS next to the bitmap; otherwise
+// they stay in global memory and queries are retired one per round.
+template <bool IN_LDS>
+__global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp, int lds_n) {
+    extern __shared__ u32 sm[];
+    __shared__ u32 hist[32];
+    __shared__ u32 order[32];
+    const proj_problem& P = problems[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int n = P.frm.n, nq = P.q.n;
+    const int words = (n + 31) >> 5;
+    u32* blocked = sm;
+    int* lmatched = reinterpret_cast<int*>(sm + ((lds_n + 31) >> 5) + 1);
+    u32* claim = reinterpret_cast<u32*>(lmatched + lds_n);
+    for (int i = lane; i < words; i += 64) {
+        blocked[i] = 0;
+    }
+    if (lane < 32) {
+        hist[lane] = 0;
+    }
+    for (int i = lane; i < n; i += 64) {
+        if (IN_LDS) {
+            lmatched[i] = -1;
+            claim[i] = 0x7FFFFFFFu;
+        }
+        else {
+            P.matched[i] = -1;
+        }
+    }
+    __syncthreads();
+
+    const bool excl = pp.kind != kOneWay;
+    const int needed = pp.kind == kFrameLms ? 2 : 1;
+    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr : (pp.kind == kSim3 ? kThrLow : kThrHigh);
+    u32 mynum = 0;
+    for (int base = 0; base < nq; base += 64) {
+        const int mq = base + lane;
+        u64 mykeys[kTopK];
+        u32 mytot = 0;
+        bool done = true;
+        bool blocks = true;
+#pragma unroll
+        for (int k = 0; k < kTopK; ++k) {
+            mykeys[k] = kNoKey;
+        }
+        if (mq < nq) {
+            mytot = P.totals[mq];
+            done = !P.q.valid[mq] || mytot == 0;
+            const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(P.lists + (size_t)mq * kTopK);
+#pragma unroll
+            for (int k = 0; k < kTopK / 2; ++k) {
+                const ulonglong2 v = lp[k];
+                mykeys[2 * k] = v.x;
+                mykeys[2 * k + 1] = v.y;
+            }
+            blocks = (pp.kind == kFrameKeyfrm || pp.kind == kSim3) ? true : (P.q.has_obs ? P.q.has_obs[mq] != 0 : true);
+        }
+        int myacc = -1;
+        while (true) {
+            u64 best = kNoKey, second = kNoKey;
+            int found = 0;
+            if (!done) {
+#pragma unroll
+                for (int k = 0; k < kTopK; ++k) {
+                    const u64 key = mykeys[k];
+                    if (key != kNoKey && found < 2) {
+                        const u32 idx = key_idx(key);
+                        const bool b = excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u);
+                        if (!b) {
+                            if (found == 0) {
+                                best = key;
+                            }
+                            else {
+                                second = key;
+                            }
+                            ++found;
+                        }
+                    }
+                }
+            }
+            // A rescan can only matter if an unlisted candidate (whose distance is at least the last
+            // listed one) could still be accepted or could change the ratio test.
+            bool need_rescan = false;
+            bool second_irrelevant = false;
+            if (!done && found < needed && mytot > (u32)kTopK) {
+                const u32 last_d = key_dist(mykeys[kTopK - 1]);
+                if (found == 0) {
+                    need_rescan = last_d <= athr;
+                }
+                else {
+                    const u32 bd = key_dist(best);
+                    if (bd <= kThrHigh) {
+                        need_rescan = (float)bd > __fmul_rn(pp.lowe, (float)last_d);
+                        second_irrelevant = !need_rescan;
+                    }
+                }
+            }
+            const bool live = !done && !need_rescan && best != kNoKey;
+            const bool accept = live && (second_irrelevant ? true : accept_rule(pp, P.frm, best, second));
+            const u32 bidx = key_idx(best);
+            const u64 rescan_mask = __ballot(need_rescan);
+            const int first_rescan = rescan_mask ? __ffsll((long long)rescan_mask) - 1 : 64;
+            int stop;
+            if (!excl) {
+                stop = 64; // no interaction between queries
+            }
+            else if (IN_LDS) {
+                const bool part = accept && lane < first_rescan;
+                if (part) {
+                    atomicMin(&claim[bidx], (u32)lane);
+                }
+                __syncthreads();
+                bool conflict = false;
+                if (live && lane < first_rescan) {
+                    conflict = claim[bidx] < (u32)lane;
+                    if (needed == 2 && second != kNoKey) {
+                        conflict |= claim[key_idx(second)] < (u32)lane;
+                    }
+                }
+                const u64 cmask = __ballot(conflict);
+                const int first_conflict = cmask ? __ffsll((long long)cmask) - 1 : 64;
+                stop = min(first_rescan, first_conflict);
+                __syncthreads();
+                if (part) {
+                    claim[bidx] = 0x7FFFFFFFu;
+                }
+            }
+            else {
+                const u64 undone = __ballot(!done);
+                const int first = undone ? __ffsll((long long)undone) - 1 : 64;
+                stop = min(first_rescan, first == 64 ? 64 : first + 1);
+            }
+            if (accept && lane < stop) {
+                if (excl) {
+                    if (IN_LDS) {
+                        lmatched[bidx] = mq;
+                    }
+                    else {
+                        P.matched[bidx] = mq;
+                    }
+                    if (blocks) {
+                        atomicOr(&blocked[bidx >> 5], 1u << (bidx & 31));
+                    }
+                    ++mynum;
+                }
+                myacc = (int)bidx;
+            }
+            if (lane < stop) {
+                done = true;
+            }
+            __syncthreads();
+            if (stop == 64) {
+                break;
+            }
+            if (stop == first_rescan) {
+                const int qi = base + stop;
+                query_ctx c;
+                make_query_ctx(pp, P.frm, P.q, qi, c);
+                u32 qd[8];
+                load_desc(P.q.desc + 32 * (size_t)qi, qd);
+                u64 top2[2];
+                u32 t2;
+                window_topk<64, 2>(P.frm, c, qd, P.occupied, blocked, top2, t2);
+                if (top2[0] != kNoKey && accept_rule(pp, P.frm, top2[0], top2[1])) {
+                    const u32 ridx = key_idx(top2[0]);
+                    const bool rblocks = __shfl((int)blocks, stop) != 0;
+                    if (lane == stop) {
+                        if (IN_LDS) {
+                            lmatched[ridx] = qi;
+                        }
+                        else {
+                            P.matched[ridx] = qi;
+                        }
+                        if (rblocks) {
+                            atomicOr(&blocked[ridx >> 5], 1u << (ridx & 31));
+                        }
+                        ++mynum;
+                        myacc = (int)ridx;
+                    }
+                }
+                if (lane == stop) {
+                    done = true;
+                }
+                __syncthreads();
+            }
+        }
+        if (mq < nq) {
+            P.acc_idx[mq] = myacc;
+        }
+    }
+    __syncthreads();
+    u32 num = wave_sum_u32(mynum);
+
+    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm);
+    if (orient) {
+        // rotation consistency, match/angle_checker.h: keep the three fullest of 30 bins.  Every lane
+        // revisits exactly the queries it wrote acc_idx for.
+        for (int qi = lane; qi < nq; qi += 64) {
+            const int idx = P.acc_idx[qi];
+            if (0 <= idx) {
+                int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                if (bin < 0 || 30 <= bin) {
+                    *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
+                    bin = 0;
+                }
+                atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            ovs_sort::index_sort_by_size(hist, order, 30);
+        }
+        __syncthreads();
+        const u32 v0 = order[0], v1 = order[1], v2 = order[2];
+        u32 removed = 0;
+        for (int qi = lane; qi < nq; qi += 64) {
+            const int idx = P.acc_idx[qi];
+            if (0 <= idx) {
+                int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                bin = (bin < 0 || 30 <= bin) ? 0 : bin;
+                if ((u32)bin != v0 && (u32)bin != v1 && (u32)bin != v2) {
+                    if (IN_LDS) {
+                        lmatched[idx] = -2;
+                    }
+                    else {
+                        P.matched[idx] = -2;
+                    }
+                    ++removed;
+                }
+            }
+        }
+        removed = wave_sum_u32(removed);
+        num -= removed;
+        __syncthreads();
+    }
+    if (IN_LDS && excl) {
+        for (int i = lane; i < n; i += 64) {
+            P.matched[i] = lmatched[i];
+        }
+    }
+    if (lane == 0 && excl) {
+        *P.num_matches = num;
+    }
+}
+
+// ---- get_keypoints_in_cell ------------------------------------------------------------------------
+// One wavefront per query.  count_only: out_counts[q] = number of indices; otherwise the indices
+// are written in the reference's order at out_indices[offsets[q]..].
+__global__ __launch_bounds__(256) void k_window_list(frame_dev f, int nq, const float* __restrict__ ref_xy, const float* __restrict__ margin,
+                                                     const int* __restrict__ min_level, const int* __restrict__ max_level,
+                                                     int count_only, u32* __restrict__ out_counts, const u32* __restrict__ offsets,
+                                                     u32* __restrict__ out_indices) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (qi >= nq) {
+        return;
+    }
+    query_ctx c;
+    c.rx = ref_xy[2 * qi];
+    c.ry = ref_xy[2 * qi + 1];
+    c.margin = margin[qi];
+    c.min_level = min_level ? min_level[qi] : -1;
+    c.max_level = max_level ? max_level[qi] : -1;
+    c.ugate = false;
+    c.stereo_gate = false;
+    c.xr = 0;
+    c.sl = 0;
+    u32 written = 0;
+    const window w = window_of(f.grid, c.rx, c.ry, c.margin);
+    if (!w.empty) {
+        const int R = (int)f.grid.num_rows;
+        u32* out = count_only ? nullptr : out_indices + offsets[qi];
+        for (int cx = w.min_cx; cx <= w.max_cx; ++cx) {
+            const u32 s = f.cell_start[cx * R + w.min_cy], e = f.cell_start[cx * R + w.max_cy + 1];
+            for (u32 j0 = s; j0 < e; j0 += 64) {
+                const u32 j = j0 + lane;
+                bool pass = false;
+                uint4 en = make_uint4(0, 0, 0, 0);
+                if (j < e) {
+                    en = f.g_entry[j];
+                    pass = passes_gates(f, c, en, nullptr, nullptr, false);
+                }
+                const u64 bits = __ballot(pass);
+                if (pass && out) {
+                    out[written + __popcll(bits & ((1ull << lane) - 1ull))] = en.w;
+                }
+                written += __popcll(bits);
+            }
+        }
+    }
+    if (count_only && lane == 0) {
+        out_counts[qi] = written;
+    }
+}
+
+// Fills the problem descriptors of a batch of consecutive-frame matches from device-side counts and
+// splits the query fields out of the previous frame's keypoints.  grid = (ceil(cap / 256), n_frames).
+__global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
+                                                     const int* __restrict__ counts, int n_frames, int cap,
+                                                     const float* __restrict__ reproj_xy, ovs_grid grid,
+                                                     const float* __restrict__ scale_factors, int num_levels,
+                                                     u32* cell_start, uint4* g_entry, uint4* g_desc, int ncell,
+                                                     int* sl, float* ang, uint8_t* valid, u64* lists, u32* totals, int* acc,
+                                                     int* matched, u32* num_matches, int* err, proj_problem* problems) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (f == 0) {
+        if (i < cap) {
+            matched[i] = -1;
+        }
+        if (i == 0) {
+            num_matches[0] = 0;
+        }
+        return;
+    }
+    const int n_last = max(min(counts[f - 1], cap), 0);
+    const size_t qo = (size_t)f * cap;
+    if (i < cap) {
+        const ovs_keypoint kp = kps[(size_t)(f - 1) * cap + min(i, max(n_last - 1, 0))];
+        sl[qo + i] = kp.octave;
+        ang[qo + i] = kp.angle;
+        valid[qo + i] = (i < n_last && !(reproj_xy[2 * (qo + i)] < -1e30f)) ? 1 : 0;
+        acc[qo + i] = -1;
+    }
+    if (i == 0) {
+        proj_problem P;
+        P.frm.n = max(min(counts[f], cap), 0);
+        P.frm.kps = kps + qo;
+        P.frm.desc = desc + qo * 32;
+        P.frm.sxr = nullptr;
+        P.frm.scale_factors = scale_factors;
+        P.frm.num_levels = num_levels;
+        P.frm.grid = grid;
+        P.frm.cell_start = cell_start + (size_t)f * (ncell + 1);
+        P.frm.g_entry = g_entry + qo;
+        P.frm.g_desc = g_desc + 2 * qo;
+        P.q.n = n_last;
+        P.q.reproj_xy = reproj_xy + 2 * qo;
+        P.q.x_right = nullptr;
+        P.q.scale_level = sl + qo;
+        P.q.angle = ang + qo;
+        P.q.desc = desc + (size_t)(f - 1) * cap * 32;
+        P.q.valid = valid + qo;
+        P.q.has_obs = nullptr;
+        P.occupied = nullptr;
+        P.lists = lists + qo * kTopK;
+        P.totals = totals + qo;
+        P.matched = matched + qo;
+        P.num_matches = num_matches + f;
+        P.acc_idx = acc + qo;
+        P.err = err;
+        problems[f - 1] = P;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------
+// LDS plan of k_proj_resolve: the claim bitmap always lives in LDS; the per-keypoint `matched` and
+// `claim` arrays join it when everything fits in 64 KB.
+int resolve_lds_n(int n) { return (static_cast<size_t>(n) * 8 + (static_cast<size_t>(n) / 32 + 2) * 4 <= 60 * 1024) ? std::max(n, 1) : 0; }
+size_t resolve_lds_bytes(int n, int lds_n) {
+    if (lds_n > 0) {
+        return (static_cast<size_t>((lds_n + 31) / 32) + 1) * 4 + static_cast<size_t>(lds_n) * 8;
+    }
+    return (static_cast<size_t>((n + 31) / 32) + 1) * 4;
+}
+
+int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
+    const int lds_n = resolve_lds_n(max_n);
+    const size_t bytes = resolve_lds_bytes(max_n, lds_n);
+    if (lds_n > 0) {
+        OVS_LAUNCH("k_proj_resolve", k_proj_resolve<true>, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+    }
+    else {
+        if (bytes > 64 * 1024) {
+            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        static_cast<int>(bytes)));
+        }
+        OVS_LAUNCH("k_proj_resolve", k_proj_resolve<false>, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, 0);
+    }
+    return OVS_OK;
+}
+
+int grid_lds_bytes(const ovs_grid& g) { return static_cast<int>((2 * g.num_cols * g.num_rows + 1) * sizeof(u32)); }
+
+int validate_frame(const ovs_frame_view* f) {
+    if (!f || f->num_keypts < 0 || (f->num_keypts > 0 && (!f->undist_keypts || !f->descriptors)) || !f->scale_factors
+        || f->num_scale_levels <= 0) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid frame view");
+    }
+    if (f->num_keypts >= (1 << 20)) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 2^20 keypoints per frame are not supported");
+    }
+    const unsigned long long ncell = static_cast<unsigned long long>(f->grid.num_cols) * f->grid.num_rows;
+    if (ncell == 0 || ncell > 16384) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "grids with more than 16384 cells are not supported");
+    }
+    return OVS_OK;
+}
+
+// Uploads a host frame view and builds its grid on the device.
+struct uploaded_frame {
+    frame_dev dev;
+};
+
+size_t frame_bytes(const ovs_frame_view* f) {
+    const size_t n = f->num_keypts, L = f->num_scale_levels;
+    const size_t ncell = static_cast<size_t>(f->grid.num_cols) * f->grid.num_rows;
+    return al(n * sizeof(ovs_keypoint)) + al(n * 32) + al(n * 4) + al(L * 4) + al((ncell + 1) * 4) + al(n * 4) + al(n * 16) + al(n * 32);
+}
+
+int upload_frame(const ovs_frame_view* f, carver& cv, hipStream_t st, frame_dev& out) {
+    const size_t n = f->num_keypts, L = f->num_scale_levels;
+    const size_t ncell = static_cast<size_t>(f->grid.num_cols) * f->grid.num_rows;
+    auto* d_kps = cv.take<ovs_keypoint>(n);
+    auto* d_desc = cv.take<uint8_t>(n * 32);
+    auto* d_sxr = cv.take<float>(n);
+    auto* d_sf = cv.take<float>(L);
+    auto* d_cell_start = cv.take<u32>(ncell + 1);
+    auto* d_items = cv.take<u32>(n);
+    auto* d_entry = cv.take<uint4>(n);
+    auto* d_gdesc = cv.take<uint4>(2 * n);
+    if (n) {
+        OVS_HIP(hipMemcpyAsync(d_kps, f->undist_keypts, n * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
+        OVS_HIP(hipMemcpyAsync(d_desc, f->descriptors, n * 32, hipMemcpyHostToDevice, st));
+        if (f->stereo_x_right) {
+            OVS_HIP(hipMemcpyAsync(d_sxr, f->stereo_x_right, n * 4, hipMemcpyHostToDevice, st));
+        }
+    }
+    OVS_HIP(hipMemcpyAsync(d_sf, f->scale_factors, L * 4, hipMemcpyHostToDevice, st));
+    out.n = static_cast<int>(n);
+    out.kps = d_kps;
+    out.desc = d_desc;
+    out.sxr = f->stereo_x_right ? d_sxr : nullptr;
+    out.scale_factors = d_sf;
+    out.num_levels = static_cast<int>(L);
+    out.grid = f->grid;
+    out.cell_start = d_cell_start;
+    out.g_entry = d_entry;
+    out.g_desc = d_gdesc;
+    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(1), dim3(256), grid_lds_bytes(f->grid), st,
+               d_kps, d_desc, static_cast<const int*>(nullptr), static_cast<int>(n), static_cast<int>(std::max<size_t>(n, 1)), f->grid,
+               d_cell_start, d_items, d_entry, d_gdesc);
+    return OVS_OK;
+}
+
+// Runs one projection-matching problem given host views.
+int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const uint8_t* occupied, proj_params pp,
+                   int32_t* matched_out, int32_t* best_of_query_out, uint32_t* num_matches, int device) {
+    int rc = validate_frame(frm);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    if (!q || q->n < 0 || (q->n > 0 && (!q->reproj_xy || !q->scale_level || !q->desc || !q->valid))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid query set");
+    }
+    if (pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm) && q->n > 0 && !q->angle) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "query angles are required for the orientation check");
+    }
+    if ((rc = check_device(device)) != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) {
+        return rc;
+    }
+    const size_t n = frm->num_keypts, nq = q->n;
+    const size_t total = frame_bytes(frm) + al(n) + al(nq * 8) + al(nq * 4) * 3 + al(nq * 32) + al(nq) * 2
+                         + al(nq * kTopK * 8) + al(nq * 4) * 2 + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem));
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    hipStream_t st = ctx->stream;
+
+    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) {
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+
+    proj_problem P;
+    std::memset(&P, 0, sizeof(P));
+    if ((rc = upload_frame(frm, cv, st, P.frm)) != OVS_OK) {
+        return rc;
+    }
+    auto* d_occ = cv.take<uint8_t>(n);
+    auto* d_rxy = cv.take<float>(nq * 2);
+    auto* d_xr = cv.take<float>(nq);
+    auto* d_sl = cv.take<int>(nq);
+    auto* d_ang = cv.take<float>(nq);
+    auto* d_qdesc = cv.take<uint8_t>(nq * 32);
+    auto* d_valid = cv.take<uint8_t>(nq);
+    auto* d_hasobs = cv.take<uint8_t>(nq);
+    auto* d_lists = cv.take<u64>(nq * kTopK);
+    auto* d_totals = cv.take<u32>(nq);
+    auto* d_acc = cv.take<int>(nq);
+    auto* d_matched = cv.take<int>(n);
+    auto* d_num = cv.take<u32>(1);
+    auto* d_err = cv.take<int>(1);
+    auto* d_prob = cv.take<proj_problem>(1);
+
+    if (occupied) {
+        OVS_HIP(up(d_occ, occupied, n));
+    }
+    OVS_HIP(up(d_rxy, q->reproj_xy, nq * 8));
+    if (q->x_right) {
+        OVS_HIP(up(d_xr, q->x_right, nq * 4));
+    }
+    OVS_HIP(up(d_sl, q->scale_level, nq * 4));
+    if (q->angle) {
+        OVS_HIP(up(d_ang, q->angle, nq * 4));
+    }
+    OVS_HIP(up(d_qdesc, q->desc, nq * 32));
+    OVS_HIP(up(d_valid, q->valid, nq));
+    if (q->has_observation) {
+        OVS_HIP(up(d_hasobs, q->has_observation, nq));
+    }
+    OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
+    OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
+    if (nq) {
+        OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
+    }
+
+    P.q.n = static_cast<int>(nq);
+    P.q.reproj_xy = d_rxy;
+    P.q.x_right = q->x_right ? d_xr : nullptr;
+    P.q.scale_level = d_sl;
+    P.q.angle = q->angle ? d_ang : nullptr;
+    P.q.desc = d_qdesc;
+    P.q.valid = d_valid;
+    P.q.has_obs = q->has_observation ? d_hasobs : nullptr;
+    P.occupied = occupied ? d_occ : nullptr;
+    P.lists = d_lists;
+    P.totals = d_totals;
+    P.matched = d_matched;
+    P.num_matches = d_num;
+    P.acc_idx = d_acc;
+    P.err = d_err;
+    OVS_HIP(up(d_prob, &P, sizeof(P)));
+
+    if (nq) {
+        constexpr int QPB = 256 / kGroup;
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((nq + QPB - 1) / QPB, 1), dim3(256), 0, st, d_prob, pp);
+    }
+    if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(hipGetLastError());
+
+    int err = 0;
+    uint32_t num = 0;
+    if (matched_out && n) {
+        OVS_HIP(hipMemcpyAsync(matched_out, d_matched, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (best_of_query_out && nq) {
+        OVS_HIP(hipMemcpyAsync(best_of_query_out, d_acc, nq * 4, hipMemcpyDeviceToHost, st));
+    }
+    OVS_HIP(hipMemcpyAsync(&num, d_num, 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipStreamSynchronize(st));
+    if (err != 0) {
+        return ovs::fail(err, "scale level or rotation bin out of range");
+    }
+    if (num_matches) {
+        *num_matches = num;
+    }
+    return OVS_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ovs_get_cell_indices(const ovs_grid* g, float x, float y, int* cell_x, int* cell_y) {
+    // data::get_cell_indices, src/openvslam/data/common.h:59-64 (pure host arithmetic)
+    *cell_x = ovs::cv_floor_d(static_cast<double>(x - g->min_x) * g->inv_cell_width);
+    *cell_y = ovs::cv_floor_d(static_cast<double>(y - g->min_y) * g->inv_cell_height);
+    return (0 <= *cell_x && *cell_x < static_cast<int>(g->num_cols) && 0 <= *cell_y && *cell_y < static_cast<int>(g->num_rows)) ? 1 : 0;
+}
+
+int ovs_get_keypoints_in_cell(const ovs_frame_view* frm, int n_queries,
+                              const float* ref_xy, const float* margin,
+                              const int32_t* min_level, const int32_t* max_level,
+                              uint32_t* out_indices, int cap, uint32_t* out_offsets, int device) {
+    int rc = validate_frame(frm);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    if (n_queries < 0 || !out_offsets || (n_queries > 0 && (!ref_xy || !margin)) || cap < 0 || (cap > 0 && !out_indices)) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if ((rc = check_device(device)) != OVS_OK) {
+        return rc;
+    }
+    out_offsets[0] = 0;
+    if (n_queries == 0) {
+        return OVS_OK;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) {
+        return rc;
+    }
+    const size_t nq = n_queries;
+    const size_t total = frame_bytes(frm) + al(nq * 8) + al(nq * 4) * 5 + al(static_cast<size_t>(cap) * 4 + 4);
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    hipStream_t st = ctx->stream;
+    frame_dev fd;
+    if ((rc = upload_frame(frm, cv, st, fd)) != OVS_OK) {
+        return rc;
+    }
+    auto* d_xy = cv.take<float>(nq * 2);
+    auto* d_m = cv.take<float>(nq);
+    auto* d_lo = cv.take<int>(nq);
+    auto* d_hi = cv.take<int>(nq);
+    auto* d_cnt = cv.take<u32>(nq);
+    auto* d_off = cv.take<u32>(nq);
+    auto* d_idx = cv.take<u32>(static_cast<size_t>(cap) + 1);
+    OVS_HIP(hipMemcpyAsync(d_xy, ref_xy, nq * 8, hipMemcpyHostToDevice, st));
+    OVS_HIP(hipMemcpyAsync(d_m, margin, nq * 4, hipMemcpyHostToDevice, st));
+    if (min_level) {
+        OVS_HIP(hipMemcpyAsync(d_lo, min_level, nq * 4, hipMemcpyHostToDevice, st));
+    }
+    if (max_level) {
+        OVS_HIP(hipMemcpyAsync(d_hi, max_level, nq * 4, hipMemcpyHostToDevice, st));
+    }
+    OVS_LAUNCH("k_window_list", k_window_list, dim3((n_queries + 3) / 4), dim3(256), 0, st, fd, n_queries, d_xy, d_m,
+               min_level ? d_lo : nullptr, max_level ? d_hi : nullptr, 1, d_cnt, static_cast<const u32*>(nullptr), static_cast<u32*>(nullptr));
+    std::vector<u32> counts(nq);
+    OVS_HIP(hipMemcpyAsync(counts.data(), d_cnt, nq * 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipStreamSynchronize(st));
+    unsigned long long run = 0;
+    std::vector<u32> offs(nq);
+    for (size_t i = 0; i < nq; ++i) {
+        offs[i] = static_cast<u32>(run);
+        run += counts[i];
+        out_offsets[i + 1] = static_cast<u32>(run);
+    }
+    if (run > static_cast<unsigned long long>(cap)) {
+        return ovs::fail(OVS_ERR_CAPACITY, "index buffer too small");
+    }
+    if (run == 0) {
+        return OVS_OK;
+    }
+    OVS_HIP(hipMemcpyAsync(d_off, offs.data(), nq * 4, hipMemcpyHostToDevice, st));
+    OVS_LAUNCH("k_window_list", k_window_list, dim3((n_queries + 3) / 4), dim3(256), 0, st, fd, n_queries, d_xy, d_m,
+               min_level ? d_lo : nullptr, max_level ? d_hi : nullptr, 0, d_cnt, d_off, d_idx);
+    OVS_HIP(hipMemcpyAsync(out_indices, d_idx, run * 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipStreamSynchronize(st));
+    return OVS_OK;
+}
+
+int ovs_match_current_and_last_frames(const ovs_frame_view* curr, const ovs_proj_queries* q,
+                                      const uint8_t* curr_occupied, float margin, int direction,
+                                      int last_num_scale_levels, float lowe_ratio, int check_orientation,
+                                      int32_t* matched_query, uint32_t* num_matches, int device) {
+    proj_params pp{kCurrLast, margin, direction, last_num_scale_levels, lowe_ratio, kThrHigh, check_orientation};
+    return run_projection(curr, q, curr_occupied, pp, matched_query, nullptr, num_matches, device);
+}
+
+int ovs_match_frame_and_landmarks(const ovs_frame_view* frm, const ovs_proj_queries* q,
+                                  const uint8_t* frm_occupied, float margin, float lowe_ratio,
+                                  int32_t* matched_query, uint32_t* num_matches, int device) {
+    proj_params pp{kFrameLms, margin, OVS_DIR_NONE, 0, lowe_ratio, kThrHigh, 0};
+    return run_projection(frm, q, frm_occupied, pp, matched_query, nullptr, num_matches, device);
+}
+
+int ovs_match_frame_and_keyframe(const ovs_frame_view* curr, const ovs_proj_queries* q,
+                                 const uint8_t* curr_occupied, float margin, uint32_t hamm_dist_thr,
+                                 int check_orientation,
+                                 int32_t* matched_query, uint32_t* num_matches, int device) {
+    proj_params pp{kFrameKeyfrm, margin, OVS_DIR_NONE, 0, 0.0f, hamm_dist_thr, check_orientation};
+    return run_projection(curr, q, curr_occupied, pp, matched_query, nullptr, num_matches, device);
+}
+
+int ovs_match_by_sim3_transform(const ovs_frame_view* keyfrm, const ovs_proj_queries* q,
+                                const uint8_t* keyfrm_occupied, float margin,
+                                int32_t* matched_query, uint32_t* num_matches, int device) {
+    proj_params pp{kSim3, margin, OVS_DIR_NONE, 0, 0.0f, kThrLow, 0};
+    return run_projection(keyfrm, q, keyfrm_occupied, pp, matched_query, nullptr, num_matches, device);
+}
+
+int ovs_match_keyframe_one_way(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, float margin,
+                               int32_t* best_idx_of_query, int device) {
+    proj_params pp{kOneWay, margin, OVS_DIR_NONE, 0, 0.0f, kThrHigh, 0};
+    return run_projection(keyfrm, q, nullptr, pp, nullptr, best_idx_of_query, nullptr, device);
+}
+
+int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, int n2,
+                    int32_t* out_idx2_of_1, uint32_t* num_matches) {
+    // projection.cc:618-633 -- a linear pass over n1 ints, done on the host
+    unsigned int num = 0;
+    std::fill(out_idx2_of_1, out_idx2_of_1 + n1, -1);
+    for (int i = 0; i < n1; ++i) {
+        const int idx_2 = idx2_of_1[i];
+        if (idx_2 < 0) {
+            continue;
+        }
+        if (n2 <= idx_2) {
+            return ovs::fail(OVS_ERR_OUT_OF_RANGE, "index out of range");
+        }
+        if (idx1_of_2[idx_2] == i) {
+            out_idx2_of_1[i] = idx_2;
+            ++num;
+        }
+    }
+    *num_matches = num;
+    return OVS_OK;
+}
+
+int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_t* d_desc,
+                                         const int32_t* d_counts, int n_frames, int cap,
+                                         const float* d_reproj_xy, const ovs_grid* grid,
+                                         const float* scale_factors, int num_scale_levels,
+                                         float margin, int check_orientation,
+                                         int32_t* d_matched, uint32_t* d_num_matches,
+                                         int device, void* stream_) {
+    if (!d_kps || !d_desc || !d_counts || !d_reproj_xy || !grid || !scale_factors || !d_matched || !d_num_matches
+        || n_frames <= 0 || cap <= 0 || num_scale_levels <= 0 || num_scale_levels > 64) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if (cap >= (1 << 20)) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 2^20 keypoints per frame are not supported");
+    }
+    if (reinterpret_cast<uintptr_t>(d_desc) & 15) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "descriptors must be 16-byte aligned");
+    }
+    const size_t ncell = static_cast<size_t>(grid->num_cols) * grid->num_rows;
+    if (ncell == 0 || ncell > 16384) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "grids with more than 16384 cells are not supported");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const size_t F = n_frames, fc = F * cap;
+    const size_t total = al(64 * 4) + al(F * (ncell + 1) * 4) + al(fc * 4) * 5 + al(fc * 16) + al(fc * 32) + al(fc) + al(fc * kTopK * 8)
+                         + al(256) + al(F * sizeof(proj_problem));
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    auto* d_sf = cv.take<float>(64);
+    auto* d_cell_start = cv.take<u32>(F * (ncell + 1));
+    auto* d_items = cv.take<u32>(fc);
+    auto* d_sl = cv.take<int>(fc);
+    auto* d_ang = cv.take<float>(fc);
+    auto* d_totals = cv.take<u32>(fc);
+    auto* d_acc = cv.take<int>(fc);
+    auto* d_entry = cv.take<uint4>(fc);
+    auto* d_gdesc = cv.take<uint4>(2 * fc);
+    auto* d_valid = cv.take<uint8_t>(fc);
+    auto* d_lists = cv.take<u64>(fc * kTopK);
+    auto* d_err = cv.take<int>(1);
+    auto* d_prob = cv.take<proj_problem>(F);
+    OVS_HIP(hipMemcpyAsync(d_sf, scale_factors, static_cast<size_t>(num_scale_levels) * 4, hipMemcpyHostToDevice, st));
+
+    proj_params pp{kCurrLast, margin, OVS_DIR_NONE, num_scale_levels, 0.0f, kThrHigh, check_orientation};
+    OVS_LAUNCH("k_batch_setup", k_batch_setup, dim3((cap + 255) / 256, n_frames), dim3(256), 0, st,
+               d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, num_scale_levels,
+               d_cell_start, d_entry, d_gdesc, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,
+               d_matched, d_num_matches, d_err, d_prob);
+    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
+               d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
+    if (n_frames > 1) {
+        constexpr int QPB = 256 / kGroup;
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((cap + QPB - 1) / QPB, n_frames - 1), dim3(256), 0, st, d_prob, pp);
+        if ((rc = launch_resolve(d_prob, n_frames - 1, cap, pp, st)) != OVS_OK) {
+            return rc;
+        }
+    }
+    OVS_HIP(hipGetLastError());
+    return OVS_OK;
+}
+
+} // extern "C"
