@@ -221,11 +221,64 @@ __device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, uns
     return s.mask[(long long)my * s.mask_stride + mx] == 0;
 }
 
+// Unaligned 4-byte read the compiler may lower to one dword load (gfx950 global memory accepts
+// unaligned dword accesses; the builtin keeps the choice with the compiler).
+__device__ __forceinline__ u32 load_u32_unaligned(const uint8_t* p) {
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// byte `o` (0..11) of the 12-byte window {a, b, c}
+__device__ __forceinline__ int win_byte(u32 a, u32 b, u32 c, int o) {
+    return o < 4 ? (int)((a >> (8 * o)) & 0xFF) : (o < 8 ? (int)((b >> (8 * (o - 4))) & 0xFF) : (int)((c >> (8 * (o - 8))) & 0xFF));
+}
+
+constexpr int kTileStride = 72; // bytes per LDS tile row; byte b of a row is image column min_x - 1 + b
+
+// Stage A of the FAST kernel for one strip of four horizontally adjacent pixels: the high-speed
+// rejection test on the four opposite ring pairs (0,8) (2,10) (4,12) (6,14).  A pixel that is a
+// corner at threshold t has, in every opposite pair, at least one pixel darker than v - t, or in
+// every pair at least one brighter than v + t (any arc of 9 covers one pixel of each pair).
+// Returns a 4-bit mask of the pixels that survive.
+__device__ __forceinline__ u32 fast_quick_test4(const uint8_t* tile, int trow, int strip, int t) {
+    // dwords strip, strip + 1, strip + 2 of a tile row hold columns 4 * strip - 4 .. 4 * strip + 7
+    // relative to the first pixel of the strip (byte 4 of the window)
+    const u32* r0 = reinterpret_cast<const u32*>(tile + trow * kTileStride) + strip;
+    const u32* rm2 = reinterpret_cast<const u32*>(tile + (trow - 2) * kTileStride) + strip;
+    const u32* rp2 = reinterpret_cast<const u32*>(tile + (trow + 2) * kTileStride) + strip;
+    const u32 up3 = reinterpret_cast<const u32*>(tile + (trow - 3) * kTileStride)[strip + 1];
+    const u32 dn3 = reinterpret_cast<const u32*>(tile + (trow + 3) * kTileStride)[strip + 1];
+    const u32 c0 = r0[0], c1 = r0[1], c2 = r0[2];
+    const u32 m0 = rm2[0], m1 = rm2[1], m2 = rm2[2];
+    const u32 p0 = rp2[0], p1 = rp2[1], p2 = rp2[2];
+    u32 out = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int v = win_byte(c0, c1, c2, 4 + p);
+        const int lo = v - t, hi = v + t;
+        const int x0 = (int)((dn3 >> (8 * p)) & 0xFF);  // ring 0  (0, +3)
+        const int x8 = (int)((up3 >> (8 * p)) & 0xFF);  // ring 8  (0, -3)
+        const int x2 = win_byte(p0, p1, p2, 4 + p + 2); // ring 2  (+2, +2)
+        const int x10 = win_byte(m0, m1, m2, 4 + p - 2); // ring 10 (-2, -2)
+        const int x4 = win_byte(c0, c1, c2, 4 + p + 3); // ring 4  (+3, 0)
+        const int x12 = win_byte(c0, c1, c2, 4 + p - 3); // ring 12 (-3, 0)
+        const int x6 = win_byte(m0, m1, m2, 4 + p + 2); // ring 6  (+2, -2)
+        const int x14 = win_byte(p0, p1, p2, 4 + p - 2); // ring 14 (-2, +2)
+        const bool dark = ((x0 < lo) | (x8 < lo)) & ((x2 < lo) | (x10 < lo)) & ((x4 < lo) | (x12 < lo)) & ((x6 < lo) | (x14 < lo));
+        const bool bright = ((x0 > hi) | (x8 > hi)) & ((x2 > hi) | (x10 > hi)) & ((x4 > hi) | (x12 > hi)) & ((x6 > hi) | (x14 > hi));
+        out |= (u32)(dark | bright) << p;
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts) {
-    __shared__ uint8_t tile[70 * 72];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
     __shared__ uint8_t score[66 * 68];
-    __shared__ u64 keepmask[64];
+    __shared__ unsigned short work[4096];
+    __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
     __shared__ int rowbase[65];
+    __shared__ int nwork;
     __shared__ int total;
 
     const int frame = blockIdx.y;
@@ -263,72 +316,98 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
         return;
     }
 
+    // tile rows as 18 dwords starting one pixel left of the window, so that interior column c sits
+    // at byte c + 4 of its row (strips of four interior pixels are dword aligned in LDS)
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    for (int i = tid; i < th * 72; i += 256) {
-        const int r = i / 72, c = i - r * 72;
-        if (c < tw) {
-            tile[r * 72 + c] = img[(long long)(min_y + r) * pitch + min_x + c];
+    for (int i = tid; i < th * 18; i += 256) {
+        const int r = i / 18, k = i - r * 18;
+        const int x = min_x - 1 + 4 * k;
+        const uint8_t* src = img + (long long)(min_y + r) * pitch;
+        u32 v;
+        if (x + 3 < g.w) {
+            v = load_u32_unaligned(src + x);
         }
-    }
-    for (int i = tid; i < 66 * 68; i += 256) {
-        score[i] = 0;
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int chunk = 0; chunk < 16; ++chunk) {
-        const int r = chunk * 4 + wave, c = lane;
-        if (r < ih && c < iw) {
-            score[(r + 1) * 68 + c + 1] = (uint8_t)fast_score_9_16(&tile[(r + 3) * 72 + c + 3], 72);
+        else {
+            v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (x + b < g.w) {
+                    v |= (u32)src[x + b] << (8 * b);
+                }
+            }
         }
+        reinterpret_cast<u32*>(tile)[r * 18 + k] = v;
+    }
+    for (int i = tid; i < 66 * 68 / 4; i += 256) {
+        reinterpret_cast<u32*>(score)[i] = 0;
     }
     __syncthreads();
 
     int thr = min(max(p.ini_thr, 0), 255);
+    const int min_thr = min(max(p.min_thr, 0), 255);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
+        if (tid == 0) {
+            nwork = 0;
+            total = 0;
+        }
+        if (tid < 128) {
+            keep32[tid] = 0;
+        }
+        __syncthreads();
+        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread
+        const int strip = tid & 15;
 #pragma unroll 1
-        for (int chunk = 0; chunk < 16; ++chunk) {
-            const int r = chunk * 4 + wave, c = lane;
-            bool keep = false;
-            if (r < ih && c < iw) {
-                const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
-                const int sc = sp[0];
-                if (sc >= thr) {
-                    int m = 0;
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (dy != 0 || dx != 0) {
-                                const int nb = sp[dy * 68 + dx];
-                                m = max(m, nb >= thr ? nb : 0);
-                            }
-                        }
-                    }
-                    keep = sc > m;
+        for (int k = 0; k < 4; ++k) {
+            const int r = (tid >> 4) + 16 * k;
+            if (r < ih && 4 * strip < iw) {
+                u32 m = fast_quick_test4(tile, r + 3, strip, thr);
+                m &= (1u << min(iw - 4 * strip, 4)) - 1u;
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    work[atomicAdd(&nwork, 1)] = (unsigned short)((r << 6) | (4 * strip + b));
                 }
             }
-            const u64 bits = __ballot(keep);
-            if (lane == 0) {
-                keepmask[r] = bits;
-            }
         }
         __syncthreads();
-        if (wave == 0) {
-            int cnt = __popcll(keepmask[lane]);
+        // stage B: exact score of the survivors
+        const int nw = nwork;
+        for (int i = tid; i < nw; i += 256) {
+            const int r = work[i] >> 6, c = work[i] & 63;
+            score[(r + 1) * 68 + c + 1] = (uint8_t)fast_score_9_16(&tile[(r + 3) * kTileStride + c + 4], kTileStride);
+        }
+        __syncthreads();
+        // non-maximum suppression over the survivors (every other pixel scores below the threshold)
+        int mykept = 0;
+        for (int i = tid; i < nw; i += 256) {
+            const int r = work[i] >> 6, c = work[i] & 63;
+            const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
+            const int sc = sp[0];
+            if (sc >= thr) {
+                int m = 0;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                cnt += __shfl_xor(cnt, d);
-            }
-            if (lane == 0) {
-                total = cnt;
+                for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dy != 0 || dx != 0) {
+                            const int nb = sp[dy * 68 + dx];
+                            m = max(m, nb >= thr ? nb : 0);
+                        }
+                    }
+                }
+                if (sc > m) {
+                    atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
+                    ++mykept;
+                }
             }
         }
+        if (mykept) {
+            atomicAdd(&total, mykept);
+        }
         __syncthreads();
-        const int min_thr = min(max(p.min_thr, 0), 255);
-        if (total != 0 || pass == 1) {
+        if (total != 0 || pass == 1 || min_thr == thr) {
             break;
         }
         thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
@@ -346,7 +425,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 #pragma unroll 1
         for (int chunk = 0; chunk < 16; ++chunk) {
             const int r = chunk * 4 + wave;
-            const u64 bits = keepmask[r];
+            const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
             bool keep = (bits >> lane) & 1ull;
             if (keep) {
                 const unsigned y = kBorder + ci * kCell + 3 + r;
@@ -354,15 +433,16 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
                 keep = !mask_is_zero(s, y, x, g.scale);
             }
             const u64 nb = __ballot(keep);
-            if (lane == 0) {
-                keepmask[r] = nb; // row r is only ever touched by this wave
+            if (lane == 0) { // row r is only touched by this wave
+                keep32[2 * r] = (u32)nb;
+                keep32[2 * r + 1] = (u32)(nb >> 32);
             }
         }
         __syncthreads();
     }
 
     if (wave == 0) {
-        const int cnt = __popcll(keepmask[lane]);
+        const int cnt = __popc(keep32[2 * lane]) + __popc(keep32[2 * lane + 1]);
         int inc = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -382,7 +462,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 #pragma unroll 1
     for (int chunk = 0; chunk < 16; ++chunk) {
         const int r = chunk * 4 + wave;
-        const u64 bits = keepmask[r];
+        const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
         if ((bits >> lane) & 1ull) {
             const int pos = rowbase[r] + __popcll(bits & ((1ull << lane) - 1ull));
             const u32 x = cj * kCell + 3 + lane; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
@@ -419,12 +499,14 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-constexpr int kBlurTW = 64, kBlurTH = 32;
+constexpr int kBlurRows = 8; // output rows per thread
 
+// One thread produces a strip of 4 x kBlurRows output pixels: it walks kBlurRows + 6 input rows,
+// reads the 10 source bytes of each as three dwords (the neighbouring strips' reads are the same
+// lines, served by the vector cache), keeps the last seven row-pass results in registers and emits
+// one dword per output row.  No LDS and no barrier; strips at the left / right image edge take a
+// byte path with reflected indices.
 __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t src[(kBlurTH + 6) * 72];
-    __shared__ unsigned short rowp[(kBlurTH + 6) * kBlurTW];
-
     const int frame = blockIdx.y;
     int t = blockIdx.x;
     int level = 0;
@@ -435,46 +517,56 @@ __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t
         }
     }
     const level_geom& g = p.lv[level];
-    t -= g.blur_tile_base;
-    const int ty = t / g.blur_tiles_x, tx = t - ty * g.blur_tiles_x;
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
-    const int tid = threadIdx.x;
-
+    const int strips = (g.w + 3) >> 2;
+    const int item = (t - g.blur_tile_base) * 256 + threadIdx.x;
+    const int rg = item / strips, strip = item - rg * strips;
+    const int y0 = rg * kBlurRows, x = strip * 4;
+    if (y0 >= g.h) {
+        return;
+    }
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    for (int i = tid; i < (kBlurTH + 6) * 72; i += 256) {
-        const int r = i / 72, c = i - r * 72;
-        if (c < kBlurTW + 6) {
-            const int sy = reflect101(y0 + r - 3, g.h);
-            const int sx = reflect101(x0 + c - 3, g.w);
-            src[i] = img[(long long)sy * pitch + sx];
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i / kBlurTW, c = i - r * kBlurTW;
-        const uint8_t* q = &src[r * 72 + c];
-        const int v = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
-        rowp[i] = (unsigned short)v;
-    }
-    __syncthreads();
     uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off;
-    for (int i = tid; i < kBlurTH * (kBlurTW / 4); i += 256) {
-        const int r = i / (kBlurTW / 4), c4 = (i - r * (kBlurTW / 4)) * 4;
-        const int y = y0 + r;
-        if (y >= g.h || x0 + c4 >= g.w) {
-            continue;
-        }
-        u32 packed = 0;
+    const bool interior = x >= 4 && x + 8 <= g.w;
+
+    int rp[7][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned short* q = &rowp[r * kBlurTW + c4 + k];
-            const int v = 18 * (q[0] + q[6 * kBlurTW]) + 34 * (q[kBlurTW] + q[5 * kBlurTW])
-                          + 49 * (q[2 * kBlurTW] + q[4 * kBlurTW]) + 55 * q[3 * kBlurTW];
-            const int o = min((v + (1 << 15)) >> 16, 255);
-            packed |= (u32)o << (8 * k);
+    for (int r = 0; r < kBlurRows + 6; ++r) {
+        const int sy = reflect101(y0 + r - 3, g.h);
+        const uint8_t* row = img + (long long)sy * pitch;
+        int b[10];
+        if (interior) {
+            const u32 d0 = load_u32_unaligned(row + x - 4), d1 = load_u32_unaligned(row + x), d2 = load_u32_unaligned(row + x + 4);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                b[k] = win_byte(d0, d1, d2, k + 1);
+            }
         }
-        *reinterpret_cast<u32*>(dst + (long long)y * g.pitch + x0 + c4) = packed;
+        else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                b[k] = row[reflect101(x - 3 + k, g.w)];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rp[r % 7][j] = 18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 49 * (b[j + 2] + b[j + 4]) + 55 * b[j + 3];
+        }
+        if (r >= 6) {
+            const int y = y0 + r - 6;
+            if (y < g.h) {
+                u32 packed = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // rows y-3 .. y+3 are slots (r-6) % 7 .. r % 7; the kernel is symmetric
+                    const int v = 18 * (rp[(r - 6) % 7][j] + rp[r % 7][j]) + 34 * (rp[(r - 5) % 7][j] + rp[(r - 1) % 7][j])
+                                  + 49 * (rp[(r - 4) % 7][j] + rp[(r - 2) % 7][j]) + 55 * rp[(r - 3) % 7][j];
+                    const int o = min((v + (1 << 15)) >> 16, 255);
+                    packed |= (u32)o << (8 * j);
+                }
+                *reinterpret_cast<u32*>(dst + (long long)y * g.pitch + x) = packed;
+            }
+        }
     }
 }
 
@@ -1299,9 +1391,9 @@ int build_plan(ovs_orb* h, int width, int height) {
         g.scale = h->scale_factors.at(l);
         g.patch_size = static_cast<float>(static_cast<unsigned int>(31 * h->scale_factors.at(l)));
         g.blur_tile_base = blur_tile_base;
-        g.blur_tiles_x = (g.w + kBlurTW - 1) / kBlurTW;
-        g.blur_tiles_y = (g.h + kBlurTH - 1) / kBlurTH;
-        blur_tile_base += g.blur_tiles_x * g.blur_tiles_y;
+        g.blur_tiles_x = (((g.w + 3) / 4) * ((g.h + kBlurRows - 1) / kBlurRows) + 255) / 256; // workgroups of 256 strips
+        g.blur_tiles_y = 1;
+        blur_tile_base += g.blur_tiles_x;
         g.tab_off = tab_off;
         g.area2x = 0;
         if (l >= 1) {
