@@ -101,6 +101,25 @@ __device__ __forceinline__ const uint8_t* level_ptr(const plan_dev& p, const ima
 // coefficient pairs) are built on the host exactly as OpenCV builds xofs / ialpha / yofs / ibeta.
 // One thread produces four horizontally adjacent pixels and stores them as one dword.
 // -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 load_u32_unaligned(const uint8_t* p) {
+    // the compiler may lower this to one dword load: gfx950 global memory accepts unaligned dwords
+    u32 v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// 8 bytes from an arbitrarily aligned address using aligned dword loads only (reads the 12 bytes
+// starting at the address rounded down to 4)
+__device__ __forceinline__ u64 load_8_bytes(const uint8_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const u32* q = reinterpret_cast<const u32*>(a & ~static_cast<uintptr_t>(3));
+    const u32 sh = (u32)(a & 3);
+    const u32 x0 = q[0], x1 = q[1], x2 = q[2];
+    const u32 lo = __builtin_amdgcn_alignbyte(x1, x0, sh);
+    const u32 hi = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    return ((u64)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, const int* __restrict__ tabs, int level) {
     const level_geom& g = p.lv[level];
     const level_geom& gs = p.lv[level - 1];
@@ -128,9 +147,11 @@ __global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, 
         }
     }
     else {
+        // tables: xofs[w4], xab[w4], yofs[h], yab[h] with w4 = w rounded up to 4 (16-byte aligned rows)
+        const int w4 = (g.w + 3) & ~3;
         const int* xofs = tabs + g.tab_off;
-        const int* xab = xofs + g.w;
-        const int* yofs = xab + g.w;
+        const int* xab = xofs + w4;
+        const int* yofs = xab + w4;
         const int* yab = yofs + g.h;
         const int sy = yofs[dy];
         const int sy0 = min(max(sy, 0), gs.h - 1);
@@ -139,18 +160,41 @@ __global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, 
         const int b0 = (short)(bb & 0xFFFF), b1 = (short)(bb >> 16);
         const uint8_t* r0 = src + (long long)sy0 * spitch;
         const uint8_t* r1 = src + (long long)sy1 * spitch;
+        const int4 so = *reinterpret_cast<const int4*>(xofs + dx0);
+        const int4 sa = *reinterpret_cast<const int4*>(xab + dx0);
+        const int sx[4] = {so.x, so.y, so.z, so.w};
+        const int aa[4] = {sa.x, sa.y, sa.z, sa.w};
+        const int nvalid = min(g.w - dx0, 4);
+        const int last = sx[nvalid - 1];
+        if (last + 1 - sx[0] < 8 && sx[0] + 12 <= gs.w) {
+            // the (at most) 8 source bytes of both rows: three aligned dwords per row, byte-aligned
+            // into a 64-bit window with v_alignbyte
+            const u64 w0 = load_8_bytes(r0 + sx[0]);
+            const u64 w1 = load_8_bytes(r1 + sx[0]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int dx = dx0 + k;
-            if (dx < g.w) {
-                const int sx = xofs[dx];
-                const int sx1 = min(sx + 1, gs.w - 1);
-                const int aa = xab[dx];
-                const int a0 = (short)(aa & 0xFFFF), a1 = (short)(aa >> 16);
-                const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-                const int h1 = r1[sx] * a0 + r1[sx1] * a1;
-                const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-                packed |= (u32)(v & 0xFF) << (8 * k);
+            for (int k = 0; k < 4; ++k) {
+                if (k < nvalid) {
+                    const int o = sx[k] - sx[0];
+                    const int o1 = min(sx[k] + 1, gs.w - 1) - sx[0];
+                    const int a0 = (short)(aa[k] & 0xFFFF), a1 = (short)(aa[k] >> 16);
+                    const int h0 = (int)((w0 >> (8 * o)) & 0xFF) * a0 + (int)((w0 >> (8 * o1)) & 0xFF) * a1;
+                    const int h1 = (int)((w1 >> (8 * o)) & 0xFF) * a0 + (int)((w1 >> (8 * o1)) & 0xFF) * a1;
+                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    packed |= (u32)(v & 0xFF) << (8 * k);
+                }
+            }
+        }
+        else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < nvalid) {
+                    const int sx1 = min(sx[k] + 1, gs.w - 1);
+                    const int a0 = (short)(aa[k] & 0xFFFF), a1 = (short)(aa[k] >> 16);
+                    const int h0 = r0[sx[k]] * a0 + r0[sx1] * a1;
+                    const int h1 = r1[sx[k]] * a0 + r1[sx1] * a1;
+                    const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                    packed |= (u32)(v & 0xFF) << (8 * k);
+                }
             }
         }
     }
@@ -219,14 +263,6 @@ __device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, uns
     my = min(max(my, 0), s.mask_h - 1);
     mx = min(max(mx, 0), s.mask_w - 1);
     return s.mask[(long long)my * s.mask_stride + mx] == 0;
-}
-
-// Unaligned 4-byte read the compiler may lower to one dword load (gfx950 global memory accepts
-// unaligned dword accesses; the builtin keeps the choice with the compiler).
-__device__ __forceinline__ u32 load_u32_unaligned(const uint8_t* p) {
-    u32 v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
 }
 
 // byte `o` (0..11) of the 12-byte window {a, b, c}
@@ -1073,14 +1109,28 @@ __device__ __forceinline__ float trig_sin(float v) {
     return trig_cos(__fsub_rn(PI_2, v));
 }
 
+constexpr int kKpGroup = 16; // lanes per keypoint in k_orient_desc
+
+template <int W>
+__device__ __forceinline__ int group_sum_i32(int v) {
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+        v += __shfl_xor(v, d, W);
+    }
+    return v;
+}
+
+// 16 lanes per keypoint, 16 keypoints per workgroup.  Lane g of a group owns rows g - 15 and
+// g + 1 of the radius-15 disc (integer moments, reduced across the group: exact in any order) and
+// pairs 16g .. 16g+15 of the pattern, i.e. bytes 2g and 2g+1 of the descriptor.
 __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, const uint8_t* __restrict__ blur,
                                                      const u32* __restrict__ lvl_xy, const uint8_t* __restrict__ lvl_resp,
                                                      const int* __restrict__ lvl_count,
                                                      ovs_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                      int* __restrict__ out_counts, int cap) {
     const int frame = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6); // slot in the per-frame level-keypoint arrays
+    const int gl = threadIdx.x & (kKpGroup - 1);
+    const int j = blockIdx.x * (256 / kKpGroup) + (threadIdx.x / kKpGroup); // slot in the per-frame level-keypoint arrays
     if (j >= p.kp_total_cap) {
         return;
     }
@@ -1093,21 +1143,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     }
     const level_geom& g = p.lv[level];
     const int slot = j - g.kp_base;
-    const int* counts = lvl_count + frame * p.num_levels;
-    int before = 0, total = 0;
-    bool bad = false;
-#pragma unroll 1
-    for (int l = 0; l < p.num_levels; ++l) {
-        const int c = counts[l];
-        bad |= c < 0;
-        before += (l < level) ? max(c, 0) : 0;
-        total += max(c, 0);
-    }
-    if (j == 0 && lane == 0) {
+    // per-level counts of the frame: one lane per level (num_levels <= 16 = group width)
+    const int myc = gl < p.num_levels ? lvl_count[frame * p.num_levels + gl] : 0;
+    const int bad = group_sum_i32<kKpGroup>(myc < 0 ? 1 : 0);
+    const int total = group_sum_i32<kKpGroup>(max(myc, 0));
+    const int before = group_sum_i32<kKpGroup>(gl < level ? max(myc, 0) : 0);
+    const int mycount = __shfl(myc, level, kKpGroup);
+    if (j == 0 && gl == 0) {
         // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
         out_counts[frame] = bad ? (int)0x80000000 : (total > cap ? -total : total);
     }
-    if (bad || slot >= counts[level]) {
+    if (bad || slot >= mycount) {
         return;
     }
     const int oi = before + slot;
@@ -1123,26 +1169,33 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
 
-    // ---- intensity centroid ----
+    // ---- intensity centroid: m_10 = sum u * I, m_01 = sum v * I over the disc ----
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - kHalfPatch;
-        const int d = c_umax[v < 0 ? -v : v];
-        const uint8_t* row = img + (long long)(py + v) * pitch + px;
-        int s0 = 0, s1 = 0;
-        for (int u = -d; u <= d; ++u) {
-            const int val = row[u];
-            s0 += val;
-            s1 += u * val;
-        }
-        m10 = s1;
-        m01 = v * s0;
-    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d);
-        m01 += __shfl_xor(m01, d);
+    for (int half = 0; half < 2; ++half) {
+        const int v = half == 0 ? gl - kHalfPatch : gl + 1;
+        if (v <= kHalfPatch) {
+            const int d = c_umax[v < 0 ? -v : v];
+            const uint8_t* row = img + (long long)(py + v) * pitch + px - 16;
+            int s0 = 0, s1 = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const u32 w = load_u32_unaligned(row + 4 * q);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int u = 4 * q + b - 16;
+                    const int au = u < 0 ? -u : u;
+                    const int val = au <= d ? (int)((w >> (8 * b)) & 0xFF) : 0;
+                    s0 += val;
+                    s1 += u * val;
+                }
+            }
+            m10 += s1;
+            m01 += v * s0;
+        }
     }
+    m10 = group_sum_i32<kKpGroup>(m10);
+    m01 = group_sum_i32<kKpGroup>(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // ---- rotated BRIEF on the blurred level ----
@@ -1150,10 +1203,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     const float ca = trig_cos(arad), sa = trig_sin(arad);
     const uint8_t* center = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)py * g.pitch + px;
     const int step = g.pitch;
-    u32 nib = 0;
+    u32 bits = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int8_t* pp = &c_pattern[(lane * 4 + k) * 4];
+    for (int k = 0; k < 16; ++k) {
+        const int8_t* pp = &c_pattern[(gl * 16 + k) * 4];
         const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
         const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
@@ -1161,31 +1214,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
         const int v0 = center[r0 * step + c0];
         const int v1 = center[r1 * step + c1];
-        nib |= (u32)(v0 < v1) << k;
+        bits |= (u32)(v0 < v1) << k;
     }
-    // lane l holds bits 4l..4l+3 of the descriptor: gather 8 lanes into one dword
-    u32 word = nib << (4 * (lane & 7));
-    word |= __shfl_xor(word, 1);
-    word |= __shfl_xor(word, 2);
-    word |= __shfl_xor(word, 4);
-    if ((lane & 7) == 0) {
-        reinterpret_cast<u32*>(out_desc + ((long long)frame * cap + oi) * 32)[lane >> 3] = word;
-    }
-    if (lane == 0) {
-        ovs_keypoint kp;
+    reinterpret_cast<unsigned short*>(out_desc + ((long long)frame * cap + oi) * 32)[gl] = (unsigned short)bits;
+
+    if (gl < 7) {
         float fx = (float)px, fy = (float)py;
         if (level != 0) {
             fx = __fmul_rn(fx, g.scale); // correct_keypoint_scale, orb_extractor.cc:598-606
             fy = __fmul_rn(fy, g.scale);
         }
-        kp.x = fx;
-        kp.y = fy;
-        kp.size = g.patch_size;
-        kp.angle = angle;
-        kp.response = (float)resp;
-        kp.octave = level;
-        kp.class_id = -1;
-        out_kps[(long long)frame * cap + oi] = kp;
+        u32 field;
+        switch (gl) {
+            case 0: field = __float_as_uint(fx); break;
+            case 1: field = __float_as_uint(fy); break;
+            case 2: field = __float_as_uint(g.patch_size); break;
+            case 3: field = __float_as_uint(angle); break;
+            case 4: field = __float_as_uint((float)resp); break;
+            case 5: field = (u32)level; break;
+            default: field = 0xFFFFFFFFu; break; // class_id = -1
+        }
+        reinterpret_cast<u32*>(out_kps + (long long)frame * cap + oi)[gl] = field;
     }
 }
 
@@ -1399,10 +1448,12 @@ int build_plan(ovs_orb* h, int width, int height) {
         if (l >= 1) {
             const level_geom& gs = p.lv[l - 1];
             g.area2x = is_area_fast_2x(gs.w, gs.h, g.w, g.h) ? 1 : 0;
-            tabs.resize(tab_off + 2 * g.w + 2 * g.h);
-            resize_tables(gs.w, g.w, true, tabs.data() + tab_off, tabs.data() + tab_off + g.w);
-            resize_tables(gs.h, g.h, false, tabs.data() + tab_off + 2 * g.w, tabs.data() + tab_off + 2 * g.w + g.h);
-            tab_off += 2 * g.w + 2 * g.h;
+            const int w4 = (g.w + 3) & ~3;
+            const int seg = (2 * w4 + 2 * g.h + 3) & ~3; // keeps every level's tables 16-byte aligned
+            tabs.resize(tab_off + seg, 0);
+            resize_tables(gs.w, g.w, true, tabs.data() + tab_off, tabs.data() + tab_off + w4);
+            resize_tables(gs.h, g.h, false, tabs.data() + tab_off + 2 * w4, tabs.data() + tab_off + 2 * w4 + g.h);
+            tab_off += seg;
         }
         p.max_cells = std::max(p.max_cells, g.cells_x * g.cells_y);
         p.max_ncap = std::max(p.max_ncap, g.ncap);
@@ -1703,7 +1754,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand_xy.as<u32>(), h->cand_st.as<u32>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
-    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3((p.kp_total_cap + 3) / 4, n_frames), dim3(256), 0, stream,
+    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3((p.kp_total_cap + 15) / 16, n_frames), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
                d_kps, d_desc, d_counts, cap);
     OVS_HIP(hipGetLastError());

@@ -31,3 +31,8 @@ if len(gk) == len(rk):
     print("angle diff", int((gk["angle"].view(np.uint32) != rk["angle"].view(np.uint32)).sum()),
           "resp diff", int((gk["response"] != rk["response"]).sum()),
           "desc rows diff", int((gd != rd).any(axis=1).sum()))
+a, b = ext.image_pyramid(1), ref.pyramid_level(1)
+ys, xs = np.nonzero(a != b)
+print("diff rows", np.unique(ys)[:20], "n rows", len(np.unique(ys)))
+print("diff cols", np.unique(xs)[:20], "n cols", len(np.unique(xs)))
+print("sample", [(int(y), int(x), int(a[y, x]), int(b[y, x])) for y, x in list(zip(ys, xs))[:10]])
