@@ -294,6 +294,15 @@ int ovs_stereo_compute(const ovs_image_view* left_pyr, const ovs_image_view* rig
                        float focal_x_baseline, float true_baseline,
                        float* stereo_x_right, float* depths, int device);
 
+/* The same on device-resident data: the two pyramids are the ones the extractor handles keep
+ * after ovs_orb_extract_batch_dev (frame indices select the batch entries), keypoints / descriptors
+ * / counts are the device outputs of those calls.  Enqueued on `stream`, not synchronised. */
+int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int frame_right,
+                           const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_n_left,
+                           const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_n_right, int cap,
+                           float focal_x_baseline, float true_baseline,
+                           float* d_stereo_x_right, float* d_depths, int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* match::robust, match::bow_tree                                                             */
 /* ------------------------------------------------------------------------------------------ */

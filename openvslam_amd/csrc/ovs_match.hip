@@ -5,9 +5,12 @@
 // None of this is a dense contraction, so there is no MFMA here: distances are v_xor + v_bcnt over
 // 8 dwords, selections are per-lane running minima merged by the lexicographic (distance, row) key.
 #include "ovs_match_common.h"
+#include "std_sort_port.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 using namespace ovsm;
 
@@ -21,6 +24,19 @@ __global__ __launch_bounds__(256) void k_hamming_pairs(const uint8_t* __restrict
         load_desc(a + 32 * (size_t)i, da);
         load_desc(b + 32 * (size_t)i, db);
         out[i] = hamming8(da, db);
+    }
+}
+
+// out[i] = hamming(a[ia[i]], b[ib[i]])
+__global__ __launch_bounds__(256) void k_hamming_indexed(const uint8_t* __restrict__ a, const u32* __restrict__ ia,
+                                                         const uint8_t* __restrict__ b, const u32* __restrict__ ib, long long n,
+                                                         unsigned short* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        u32 da[8], db[8];
+        load_desc(a + 32 * (size_t)ia[i], da);
+        load_desc(b + 32 * (size_t)ib[i], db);
+        out[i] = (unsigned short)hamming8(da, db);
     }
 }
 
@@ -392,27 +408,197 @@ int ovs_knn2_merge(const ovs_knn2* lists, int n_lists, int nq, ovs_knn2* out) {
     return OVS_OK;
 }
 
-// ---- not yet on the device -------------------------------------------------------------------------
-int ovs_stereo_compute(const ovs_image_view*, const ovs_image_view*, int, const ovs_keypoint*, int, const ovs_keypoint*, int,
-                       const uint8_t*, const uint8_t*, const float*, const float*, float, float, float*, float*, int) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
-}
-int ovs_brute_force_match(const uint8_t*, const float*, int, const uint8_t*, const float*, const uint8_t*, int, float, int,
-                          int32_t*, uint32_t*, int) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
-}
-int ovs_bow_match_frame_and_keyframe(const ovs_bow_feat_vec*, const uint8_t*, const float*, const uint8_t*, int,
-                                     const ovs_bow_feat_vec*, const uint8_t*, const float*, int, float, int, int32_t*, uint32_t*, int) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
-}
-int ovs_bow_match_keyframes(const ovs_bow_feat_vec*, const uint8_t*, const float*, const uint8_t*, int,
-                            const ovs_bow_feat_vec*, const uint8_t*, const float*, const uint8_t*, int, float, int, int32_t*, uint32_t*, int) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
-}
-int ovs_match_for_triangulation(const ovs_bow_feat_vec*, const uint8_t*, const ovs_keypoint*, const double*, const float*, const uint8_t*, int,
-                                const ovs_bow_feat_vec*, const uint8_t*, const ovs_keypoint*, const double*, const float*, const uint8_t*, int,
-                                const double*, const double*, const float*, int, int, uint32_t*, uint32_t*, int) {
-    return ovs::fail(OVS_ERR_UNSUPPORTED, "not implemented yet");
+int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
+                                const ovs_keypoint* undist_keypts_1, const double* bearings_1,
+                                const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,
+                                const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2,
+                                const ovs_keypoint* undist_keypts_2, const double* bearings_2,
+                                const float* stereo_x_right_2, const uint8_t* has_lm_2, int n2,
+                                const double* E_12, const double* epipole_in_2,
+                                const float* scale_factors_1, int num_scale_levels_1,
+                                int check_orientation,
+                                uint32_t* pairs, uint32_t* num_matches, int device) {
+    // robust::match_for_triangulation (robust.cc:18-172).  The Hamming distances of all bucket
+    // pairs are computed on the device in one launch; the selection loop with its double-precision
+    // epipolar gates (std::acos, robust.cc:317-335) runs on the host in the reference's order, so
+    // the gates use the very libm calls the reference uses.
+    if (!vec_1 || !vec_2 || n1 < 0 || n2 < 0 || !E_12 || !epipole_in_2 || !scale_factors_1 || !pairs || !num_matches
+        || (n1 > 0 && (!descs_1 || !undist_keypts_1 || !bearings_1)) || (n2 > 0 && (!descs_2 || !undist_keypts_2 || !bearings_2))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    // 1. enumerate the (idx_1, idx_2) pairs of the merge-join in loop order
+    struct bucket {
+        u32 a_lo, a_hi, b_lo, b_hi;
+        size_t pair_base;
+    };
+    std::vector<bucket> buckets;
+    std::vector<u32> pa, pb;
+    {
+        int a = 0, b = 0;
+        while (a != vec_1->num_nodes && b != vec_2->num_nodes) {
+            if (vec_1->node_ids[a] == vec_2->node_ids[b]) {
+                bucket bk{vec_1->offsets[a], vec_1->offsets[a + 1], vec_2->offsets[b], vec_2->offsets[b + 1], pa.size()};
+                for (u32 x = bk.a_lo; x < bk.a_hi; ++x) {
+                    if (static_cast<int>(vec_1->indices[x]) >= n1) {
+                        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
+                    }
+                    for (u32 y = bk.b_lo; y < bk.b_hi; ++y) {
+                        if (static_cast<int>(vec_2->indices[y]) >= n2) {
+                            return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
+                        }
+                        pa.push_back(vec_1->indices[x]);
+                        pb.push_back(vec_2->indices[y]);
+                    }
+                }
+                buckets.push_back(bk);
+                ++a;
+                ++b;
+            }
+            else if (vec_1->node_ids[a] < vec_2->node_ids[b]) {
+                a = static_cast<int>(std::lower_bound(vec_1->node_ids, vec_1->node_ids + vec_1->num_nodes, vec_2->node_ids[b]) - vec_1->node_ids);
+            }
+            else {
+                b = static_cast<int>(std::lower_bound(vec_2->node_ids, vec_2->node_ids + vec_2->num_nodes, vec_1->node_ids[a]) - vec_2->node_ids);
+            }
+        }
+    }
+    // 2. distances on the device
+    const size_t np = pa.size();
+    std::vector<unsigned short> dist(np);
+    if (np) {
+        ovs::device_guard guard(device);
+        thread_ctx* ctx = ctx_for(device);
+        if ((rc = ensure_stream(ctx)) != OVS_OK) return rc;
+        const size_t s1 = n1, s2 = n2;
+        if ((rc = ctx->arena.reserve(al(s1 * 32) + al(s2 * 32) + 2 * al(np * 4) + al(np * 2))) != OVS_OK) return rc;
+        carver cv;
+        cv.base = ctx->arena.as<uint8_t>();
+        auto* d1 = cv.take<uint8_t>(s1 * 32);
+        auto* d2 = cv.take<uint8_t>(s2 * 32);
+        auto* da = cv.take<u32>(np);
+        auto* db = cv.take<u32>(np);
+        auto* dd = cv.take<unsigned short>(np);
+        OVS_HIP(hipMemcpyAsync(d1, descs_1, s1 * 32, hipMemcpyHostToDevice, ctx->stream));
+        OVS_HIP(hipMemcpyAsync(d2, descs_2, s2 * 32, hipMemcpyHostToDevice, ctx->stream));
+        OVS_HIP(hipMemcpyAsync(da, pa.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+        OVS_HIP(hipMemcpyAsync(db, pb.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
+        OVS_LAUNCH("k_hamming_indexed", k_hamming_indexed, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d1, da, d2, db, static_cast<long long>(np), dd);
+        OVS_HIP(hipMemcpyAsync(dist.data(), dd, np * 2, hipMemcpyDeviceToHost, ctx->stream));
+        OVS_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    // 3. the reference's selection loop over the precomputed distances
+    unsigned int num = 0;
+    std::vector<bool> is_already_matched_in_keyfrm_2(n2, false);
+    std::vector<int> matched_indices_2_in_keyfrm_1(n1, -1);
+    std::vector<std::pair<float, int>> angle_entries; // (delta angle, idx_1) in append order
+    auto check_epipolar_constraint = [&](const double* bearing_1, const double* bearing_2, float bearing_1_scale_factor) {
+        double e[3];
+        for (int r = 0; r < 3; ++r) {
+            e[r] = E_12[3 * r] * bearing_2[0] + E_12[3 * r + 1] * bearing_2[1] + E_12[3 * r + 2] * bearing_2[2];
+        }
+        const double dot = e[0] * bearing_1[0] + e[1] * bearing_1[1] + e[2] * bearing_1[2];
+        const double norm = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+        const double cos_residual = dot / norm;
+        const double residual_rad = M_PI / 2.0 - std::abs(std::acos(cos_residual));
+        constexpr double residual_rad_thr = 0.2 * M_PI / 180.0;
+        return residual_rad < residual_rad_thr * bearing_1_scale_factor;
+    };
+    for (const bucket& bk : buckets) {
+        const size_t nb = bk.b_hi - bk.b_lo;
+        for (u32 x = bk.a_lo; x < bk.a_hi; ++x) {
+            const u32 idx_1 = vec_1->indices[x];
+            if (has_lm_1 && has_lm_1[idx_1]) {
+                continue;
+            }
+            const bool is_stereo_keypt_1 = 0 <= (stereo_x_right_1 ? stereo_x_right_1[idx_1] : -1.0f);
+            const ovs_keypoint& keypt_1 = undist_keypts_1[idx_1];
+            if (keypt_1.octave < 0 || num_scale_levels_1 <= keypt_1.octave) {
+                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "octave out of range");
+            }
+            const double* bearing_1 = bearings_1 + 3 * static_cast<size_t>(idx_1);
+            unsigned int best_hamm_dist = kThrLow;
+            int best_idx_2 = -1;
+            for (u32 y = bk.b_lo; y < bk.b_hi; ++y) {
+                const u32 idx_2 = vec_2->indices[y];
+                if (has_lm_2 && has_lm_2[idx_2]) {
+                    continue;
+                }
+                if (is_already_matched_in_keyfrm_2[idx_2]) {
+                    continue;
+                }
+                const bool is_stereo_keypt_2 = 0 <= (stereo_x_right_2 ? stereo_x_right_2[idx_2] : -1.0f);
+                const double* bearing_2 = bearings_2 + 3 * static_cast<size_t>(idx_2);
+                const unsigned int hamm_dist = dist[bk.pair_base + static_cast<size_t>(x - bk.a_lo) * nb + (y - bk.b_lo)];
+                if (kThrLow < hamm_dist || best_hamm_dist < hamm_dist) {
+                    continue;
+                }
+                if (!is_stereo_keypt_1 && !is_stereo_keypt_2) {
+                    const double cos_dist = epipole_in_2[0] * bearing_2[0] + epipole_in_2[1] * bearing_2[1] + epipole_in_2[2] * bearing_2[2];
+                    constexpr double cos_dist_thr = 0.99862953475;
+                    if (cos_dist_thr < cos_dist) {
+                        continue;
+                    }
+                }
+                if (check_epipolar_constraint(bearing_1, bearing_2, scale_factors_1[keypt_1.octave])) {
+                    best_idx_2 = static_cast<int>(idx_2);
+                    best_hamm_dist = hamm_dist;
+                }
+            }
+            if (best_idx_2 < 0) {
+                continue;
+            }
+            is_already_matched_in_keyfrm_2[best_idx_2] = true;
+            matched_indices_2_in_keyfrm_1[idx_1] = best_idx_2;
+            ++num;
+            if (check_orientation) {
+                angle_entries.emplace_back(keypt_1.angle - undist_keypts_2[best_idx_2].angle, static_cast<int>(idx_1));
+            }
+        }
+    }
+    if (check_orientation) {
+        // match::angle_checker (angle_checker.h:72-134): 30 bins, the three fullest stay
+        unsigned hist[30] = {0};
+        std::vector<int> bins(angle_entries.size());
+        for (size_t i = 0; i < angle_entries.size(); ++i) {
+            float delta_angle = angle_entries[i].first;
+            if (delta_angle < 0.0) {
+                delta_angle += 360.0;
+            }
+            if (360.0 <= delta_angle) {
+                delta_angle -= 360.0;
+            }
+            const int bin = static_cast<int>(lrintf(delta_angle * (1.0f / 30)));
+            if (bin < 0 || 30 <= bin) {
+                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "rotation bin out of range");
+            }
+            bins[i] = bin;
+            ++hist[bin];
+        }
+        unsigned order[30];
+        ovs_sort::index_sort_by_size(hist, order, 30);
+        for (size_t i = 0; i < angle_entries.size(); ++i) {
+            const unsigned bin = static_cast<unsigned>(bins[i]);
+            if (bin != order[0] && bin != order[1] && bin != order[2]) {
+                matched_indices_2_in_keyfrm_1[angle_entries[i].second] = -1;
+                --num;
+            }
+        }
+    }
+    unsigned k = 0;
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (matched_indices_2_in_keyfrm_1[idx_1] < 0) {
+            continue;
+        }
+        pairs[2 * k] = static_cast<uint32_t>(idx_1);
+        pairs[2 * k + 1] = static_cast<uint32_t>(matched_indices_2_in_keyfrm_1[idx_1]);
+        ++k;
+    }
+    *num_matches = num;
+    return OVS_OK;
 }
 
 } // extern "C"

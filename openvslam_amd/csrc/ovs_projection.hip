@@ -35,7 +35,9 @@ enum proj_kind {
     kFrameLms = 1,    // projection::match_frame_and_landmarks
     kFrameKeyfrm = 2, // projection::match_frame_and_keyframe
     kSim3 = 3,        // projection::match_by_Sim3_transform
-    kOneWay = 4       // one direction of projection::match_keyframes_mutually
+    kOneWay = 4,      // one direction of projection::match_keyframes_mutually
+    kRange = 5        // robust::brute_force_match / bow_tree::match_*: every query names one contiguous
+                      // range of the candidate list; best <= 50 and Lowe's ratio against the runner-up
 };
 
 struct frame_dev {
@@ -60,6 +62,8 @@ struct query_dev {
     const uint8_t* desc;
     const uint8_t* valid;
     const uint8_t* has_obs;
+    const u32* range_lo; // kRange: candidates of query i are entries [range_lo[i], range_hi[i])
+    const u32* range_hi;
 };
 
 struct proj_params {
@@ -70,6 +74,8 @@ struct proj_params {
     float lowe;
     u32 thr;
     int check_orientation;
+    int angle_sign;       // +1: delta = query angle - candidate angle, -1: the reverse
+    int per_query_output; // the rotation check clears the query's own result instead of the candidate's slot
 };
 
 struct proj_problem {
@@ -230,9 +236,24 @@ struct query_ctx {
     bool ugate;               // unsigned level gate of projection.cc:390,515,598
     u32 sl;
     bool stereo_gate;
+    bool ranged; // kRange: no window, no geometric gates
+    u32 lo, hi;
 };
 
 __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const frame_dev& f, const query_dev& q, int qi, query_ctx& c) {
+    c.ranged = false;
+    c.lo = c.hi = 0;
+    if (pp.kind == kRange) {
+        c.ranged = true;
+        c.lo = q.range_lo[qi];
+        c.hi = q.range_hi[qi];
+        c.rx = c.ry = c.margin = c.xr = 0.0f;
+        c.min_level = c.max_level = -1;
+        c.ugate = false;
+        c.sl = 0;
+        c.stereo_gate = false;
+        return true;
+    }
     const int sl = q.scale_level[qi];
     if (sl < 0 || f.num_levels <= sl) {
         return false;
@@ -287,6 +308,13 @@ __device__ __forceinline__ u32 key_idx(u64 k) { return (u32)(k & 0xFFFFFu); }
 // the projection loops that do not depend on earlier queries
 __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx& c, const uint4& en, const uint8_t* occupied, const u32* blocked,
                                              bool matcher_gates) {
+    if (c.ranged) {
+        const u32 ridx = en.w;
+        if (occupied && occupied[ridx]) {
+            return false;
+        }
+        return !(blocked && ((blocked[ridx >> 5] >> (ridx & 31)) & 1u));
+    }
     const int oct = (int)en.z;
     const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
     if (check_level) {
@@ -341,12 +369,16 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
         top[k] = kNoKey;
     }
     total = 0;
-    const window w = window_of(f.grid, c.rx, c.ry, c.margin);
-    if (w.empty) {
-        return;
+    window w;
+    w.min_cx = w.max_cx = w.min_cy = w.max_cy = 0;
+    if (!c.ranged) {
+        w = window_of(f.grid, c.rx, c.ry, c.margin);
+        if (w.empty) {
+            return;
+        }
     }
     const int R = (int)f.grid.num_rows;
-    const int ncx = w.max_cx - w.min_cx + 1;
+    const int ncx = c.ranged ? 1 : w.max_cx - w.min_cx + 1;
     u64 loc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -355,7 +387,13 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
     u32 cnt = 0, posbase = 0;
     for (int cb = 0; cb < ncx; cb += G) {
         u32 s = 0, e = 0;
-        if (cb + gl < ncx) {
+        if (c.ranged) {
+            if (gl == 0) {
+                s = c.lo;
+                e = c.hi;
+            }
+        }
+        else if (cb + gl < ncx) {
             const int cx = w.min_cx + cb + gl;
             s = f.cell_start[cx * R + w.min_cy];
             e = f.cell_start[cx * R + w.max_cy + 1];
@@ -471,6 +509,14 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
             const u32 sd = second == kNoKey ? kMaxDist : key_dist(second);
             return !(bl == slv && (float)bd > __fmul_rn(pp.lowe, (float)sd));
         }
+        case kRange: {
+            // robust.cc:270-281, bow_tree.cc:80-87
+            if (bd > kThrLow) {
+                return false;
+            }
+            const u32 sd = second == kNoKey ? kMaxDist : key_dist(second);
+            return !(__fmul_rn(pp.lowe, (float)sd) < (float)bd);
+        }
         case kFrameKeyfrm:
             return bd <= pp.thr;
         case kSim3:
@@ -522,8 +568,8 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     __syncthreads();
 
     const bool excl = pp.kind != kOneWay;
-    const int needed = pp.kind == kFrameLms ? 2 : 1;
-    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr : (pp.kind == kSim3 ? kThrLow : kThrHigh);
+    const int needed = (pp.kind == kFrameLms || pp.kind == kRange) ? 2 : 1;
+    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr : ((pp.kind == kSim3 || pp.kind == kRange) ? kThrLow : kThrHigh);
     u32 mynum = 0;
     for (int base = 0; base < nq; base += 64) {
         const int mq = base + lane;
@@ -545,7 +591,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 mykeys[2 * k] = v.x;
                 mykeys[2 * k + 1] = v.y;
             }
-            blocks = (pp.kind == kFrameKeyfrm || pp.kind == kSim3) ? true : (P.q.has_obs ? P.q.has_obs[mq] != 0 : true);
+            blocks = (pp.kind == kFrameKeyfrm || pp.kind == kSim3 || pp.kind == kRange) ? true : (P.q.has_obs ? P.q.has_obs[mq] != 0 : true);
         }
         int myacc = -1;
         while (true) {
@@ -581,7 +627,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 }
                 else {
                     const u32 bd = key_dist(best);
-                    if (bd <= kThrHigh) {
+                    if (bd <= athr) {
                         need_rescan = (float)bd > __fmul_rn(pp.lowe, (float)last_d);
                         second_irrelevant = !need_rescan;
                     }
@@ -683,14 +729,15 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     __syncthreads();
     u32 num = wave_sum_u32(mynum);
 
-    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm);
+    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm || pp.kind == kRange);
     if (orient) {
         // rotation consistency, match/angle_checker.h: keep the three fullest of 30 bins.  Every lane
         // revisits exactly the queries it wrote acc_idx for.
         for (int qi = lane; qi < nq; qi += 64) {
             const int idx = P.acc_idx[qi];
             if (0 <= idx) {
-                int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                const float qa = P.q.angle[qi], ca = P.frm.kps[idx].angle;
+                int bin = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa, ca) : __fsub_rn(ca, qa));
                 if (bin < 0 || 30 <= bin) {
                     *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
                     bin = 0;
@@ -708,10 +755,14 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         for (int qi = lane; qi < nq; qi += 64) {
             const int idx = P.acc_idx[qi];
             if (0 <= idx) {
-                int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                const float qa = P.q.angle[qi], ca = P.frm.kps[idx].angle;
+                int bin = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa, ca) : __fsub_rn(ca, qa));
                 bin = (bin < 0 || 30 <= bin) ? 0 : bin;
                 if ((u32)bin != v0 && (u32)bin != v1 && (u32)bin != v2) {
-                    if (IN_LDS) {
+                    if (pp.per_query_output) {
+                        P.acc_idx[qi] = -1;
+                    }
+                    else if (IN_LDS) {
                         lmatched[idx] = -2;
                     }
                     else {
@@ -834,6 +885,8 @@ __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restr
         P.q.desc = desc + (size_t)(f - 1) * cap * 32;
         P.q.valid = valid + qo;
         P.q.has_obs = nullptr;
+        P.q.range_lo = nullptr;
+        P.q.range_hi = nullptr;
         P.occupied = nullptr;
         P.lists = lists + qo * kTopK;
         P.totals = totals + qo;
@@ -843,6 +896,21 @@ __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restr
         P.err = err;
         problems[f - 1] = P;
     }
+}
+
+// Candidate list of the range matchers: entry j is candidate entry_idx[j]; copies its descriptor
+// next to it so that a range scan reads contiguous memory.
+__global__ __launch_bounds__(256) void k_entries_from_list(const u32* __restrict__ entry_idx, int n_entries, const uint8_t* __restrict__ desc,
+                                                           uint4* __restrict__ g_entry, uint4* __restrict__ g_desc) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_entries) {
+        return;
+    }
+    const u32 i = entry_idx[j];
+    g_entry[j] = make_uint4(0u, 0u, 0u, i);
+    const u32* d = reinterpret_cast<const u32*>(desc + 32 * (size_t)i);
+    g_desc[2 * j] = make_uint4(d[0], d[1], d[2], d[3]);
+    g_desc[2 * j + 1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
 // ---- host side ------------------------------------------------------------------------------------
@@ -1062,6 +1130,205 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     return OVS_OK;
 }
 
+// A matching problem whose queries each scan one contiguous range of a candidate list
+// (robust::brute_force_match: the whole list; bow_tree::match_*: the bucket of the query's node).
+struct ranged_problem {
+    const uint8_t* cand_descs = nullptr; // n_cand x 32
+    const float* cand_angles = nullptr;  // n_cand or nullptr
+    int n_cand = 0;
+    const uint8_t* cand_occupied = nullptr; // static exclusion or nullptr
+    const u32* entry_idx = nullptr;         // candidate index of every list entry
+    int n_entries = 0;
+    const uint8_t* q_descs = nullptr; // nq x 32 (already gathered in query order)
+    const float* q_angles = nullptr;
+    const u32* q_lo = nullptr;
+    const u32* q_hi = nullptr;
+    int nq = 0;
+    float lowe = 0;
+    int check_orientation = 0, angle_sign = 1, per_query_output = 0;
+};
+
+int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out, uint32_t* num_matches, int device) {
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    if (rp.n_cand >= (1 << 20) || rp.n_entries >= (1 << 20)) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 2^20 keypoints per frame are not supported");
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) {
+        return rc;
+    }
+    const size_t n = rp.n_cand, ne = rp.n_entries, nq = rp.nq;
+    const size_t total = al(n * sizeof(ovs_keypoint)) + al(n * 32) + al(n) + al(ne * 4) + al(ne * 16) + al(ne * 32) + al(nq * 32) + al(nq * 4) * 5
+                         + al(nq) + al(nq * kTopK * 8) + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem));
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    hipStream_t st = ctx->stream;
+    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        if (!bytes) {
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    // candidate keypoints only carry the angle (read by the rotation check)
+    std::vector<ovs_keypoint> kps(n);
+    for (size_t i = 0; i < n; ++i) {
+        kps[i] = ovs_keypoint{0.f, 0.f, 0.f, rp.cand_angles ? rp.cand_angles[i] : 0.f, 0.f, 0, -1};
+    }
+    std::vector<uint8_t> valid(nq, 1);
+
+    auto* d_kps = cv.take<ovs_keypoint>(n);
+    auto* d_desc = cv.take<uint8_t>(n * 32);
+    auto* d_occ = cv.take<uint8_t>(n);
+    auto* d_eidx = cv.take<u32>(ne);
+    auto* d_entry = cv.take<uint4>(ne);
+    auto* d_gdesc = cv.take<uint4>(2 * ne);
+    auto* d_qdesc = cv.take<uint8_t>(nq * 32);
+    auto* d_ang = cv.take<float>(nq);
+    auto* d_lo = cv.take<u32>(nq);
+    auto* d_hi = cv.take<u32>(nq);
+    auto* d_totals = cv.take<u32>(nq);
+    auto* d_acc = cv.take<int>(nq);
+    auto* d_valid = cv.take<uint8_t>(nq);
+    auto* d_lists = cv.take<u64>(nq * kTopK);
+    auto* d_matched = cv.take<int>(n);
+    auto* d_num = cv.take<u32>(1);
+    auto* d_err = cv.take<int>(1);
+    auto* d_prob = cv.take<proj_problem>(1);
+
+    OVS_HIP(up(d_kps, kps.data(), n * sizeof(ovs_keypoint)));
+    OVS_HIP(up(d_desc, rp.cand_descs, n * 32));
+    if (rp.cand_occupied) {
+        OVS_HIP(up(d_occ, rp.cand_occupied, n));
+    }
+    OVS_HIP(up(d_eidx, rp.entry_idx, ne * 4));
+    OVS_HIP(up(d_qdesc, rp.q_descs, nq * 32));
+    if (rp.q_angles) {
+        OVS_HIP(up(d_ang, rp.q_angles, nq * 4));
+    }
+    OVS_HIP(up(d_lo, rp.q_lo, nq * 4));
+    OVS_HIP(up(d_hi, rp.q_hi, nq * 4));
+    OVS_HIP(up(d_valid, valid.data(), nq));
+    OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
+    OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
+    if (nq) {
+        OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
+    }
+
+    proj_problem P;
+    std::memset(&P, 0, sizeof(P));
+    P.frm.n = static_cast<int>(n);
+    P.frm.kps = d_kps;
+    P.frm.desc = d_desc;
+    P.frm.num_levels = 1;
+    P.frm.grid.num_cols = P.frm.grid.num_rows = 1;
+    P.frm.g_entry = d_entry;
+    P.frm.g_desc = d_gdesc;
+    P.q.n = static_cast<int>(nq);
+    P.q.angle = d_ang;
+    P.q.desc = d_qdesc;
+    P.q.valid = d_valid;
+    P.q.range_lo = d_lo;
+    P.q.range_hi = d_hi;
+    P.occupied = rp.cand_occupied ? d_occ : nullptr;
+    P.lists = d_lists;
+    P.totals = d_totals;
+    P.matched = d_matched;
+    P.num_matches = d_num;
+    P.acc_idx = d_acc;
+    P.err = d_err;
+    OVS_HIP(up(d_prob, &P, sizeof(P)));
+
+    proj_params pp{kRange, 0.0f, OVS_DIR_NONE, 0, rp.lowe, kThrLow, rp.check_orientation, rp.angle_sign, rp.per_query_output};
+    if (ne) {
+        OVS_LAUNCH("k_entries_from_list", k_entries_from_list, dim3((ne + 255) / 256), dim3(256), 0, st, d_eidx, static_cast<int>(ne), d_desc, d_entry, d_gdesc);
+    }
+    if (nq) {
+        constexpr int QPB = 256 / kGroup;
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((nq + QPB - 1) / QPB, 1), dim3(256), 0, st, d_prob, pp);
+    }
+    if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(hipGetLastError());
+    int err = 0;
+    uint32_t num = 0;
+    if (matched_out && n) {
+        OVS_HIP(hipMemcpyAsync(matched_out, d_matched, n * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (acc_out && nq) {
+        OVS_HIP(hipMemcpyAsync(acc_out, d_acc, nq * 4, hipMemcpyDeviceToHost, st));
+    }
+    OVS_HIP(hipMemcpyAsync(&num, d_num, 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipStreamSynchronize(st));
+    if (err != 0) {
+        return ovs::fail(err, "rotation bin out of range");
+    }
+    *num_matches = num;
+    return OVS_OK;
+}
+
+// Queries of the BoW matchers in the reference's iteration order: the merge-join over the two
+// feature vectors (bow_tree.cc:37-111), then the keypoints of the first vector's node.
+struct bow_queries {
+    std::vector<u32> q_src; // keypoint index in the first (query) set
+    std::vector<u32> lo, hi;
+    std::vector<uint8_t> descs;
+    std::vector<float> angles;
+};
+
+int build_bow_queries(const ovs_bow_feat_vec* qv, const uint8_t* q_descs, const float* q_angles, const uint8_t* q_valid, int nq_kp,
+                      const ovs_bow_feat_vec* cv_, int n_cand, bow_queries& out) {
+    int a = 0, b = 0;
+    while (a != qv->num_nodes && b != cv_->num_nodes) {
+        if (qv->node_ids[a] == cv_->node_ids[b]) {
+            for (u32 k = qv->offsets[a]; k < qv->offsets[a + 1]; ++k) {
+                const u32 idx = qv->indices[k];
+                if (static_cast<int>(idx) >= nq_kp) {
+                    return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keypoint index out of range");
+                }
+                if (q_valid && !q_valid[idx]) {
+                    continue;
+                }
+                out.q_src.push_back(idx);
+                out.lo.push_back(cv_->offsets[b]);
+                out.hi.push_back(cv_->offsets[b + 1]);
+                out.descs.insert(out.descs.end(), q_descs + 32 * static_cast<size_t>(idx), q_descs + 32 * static_cast<size_t>(idx) + 32);
+                out.angles.push_back(q_angles ? q_angles[idx] : 0.f);
+            }
+            ++a;
+            ++b;
+        }
+        else if (qv->node_ids[a] < cv_->node_ids[b]) {
+            a = static_cast<int>(std::lower_bound(qv->node_ids, qv->node_ids + qv->num_nodes, cv_->node_ids[b]) - qv->node_ids);
+        }
+        else {
+            b = static_cast<int>(std::lower_bound(cv_->node_ids, cv_->node_ids + cv_->num_nodes, qv->node_ids[a]) - cv_->node_ids);
+        }
+    }
+    const u32 total = cv_->num_nodes ? cv_->offsets[cv_->num_nodes] : 0;
+    for (u32 k = 0; k < total; ++k) {
+        if (static_cast<int>(cv_->indices[k]) >= n_cand) {
+            return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keypoint index out of range");
+        }
+    }
+    return OVS_OK;
+}
+
+int validate_bow(const ovs_bow_feat_vec* v) {
+    if (!v || v->num_nodes < 0 || (v->num_nodes > 0 && (!v->node_ids || !v->offsets || !v->indices))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid feature vector");
+    }
+    return OVS_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1153,14 +1420,14 @@ int ovs_match_current_and_last_frames(const ovs_frame_view* curr, const ovs_proj
                                       const uint8_t* curr_occupied, float margin, int direction,
                                       int last_num_scale_levels, float lowe_ratio, int check_orientation,
                                       int32_t* matched_query, uint32_t* num_matches, int device) {
-    proj_params pp{kCurrLast, margin, direction, last_num_scale_levels, lowe_ratio, kThrHigh, check_orientation};
+    proj_params pp{kCurrLast, margin, direction, last_num_scale_levels, lowe_ratio, kThrHigh, check_orientation, 1, 0};
     return run_projection(curr, q, curr_occupied, pp, matched_query, nullptr, num_matches, device);
 }
 
 int ovs_match_frame_and_landmarks(const ovs_frame_view* frm, const ovs_proj_queries* q,
                                   const uint8_t* frm_occupied, float margin, float lowe_ratio,
                                   int32_t* matched_query, uint32_t* num_matches, int device) {
-    proj_params pp{kFrameLms, margin, OVS_DIR_NONE, 0, lowe_ratio, kThrHigh, 0};
+    proj_params pp{kFrameLms, margin, OVS_DIR_NONE, 0, lowe_ratio, kThrHigh, 0, 1, 0};
     return run_projection(frm, q, frm_occupied, pp, matched_query, nullptr, num_matches, device);
 }
 
@@ -1168,20 +1435,20 @@ int ovs_match_frame_and_keyframe(const ovs_frame_view* curr, const ovs_proj_quer
                                  const uint8_t* curr_occupied, float margin, uint32_t hamm_dist_thr,
                                  int check_orientation,
                                  int32_t* matched_query, uint32_t* num_matches, int device) {
-    proj_params pp{kFrameKeyfrm, margin, OVS_DIR_NONE, 0, 0.0f, hamm_dist_thr, check_orientation};
+    proj_params pp{kFrameKeyfrm, margin, OVS_DIR_NONE, 0, 0.0f, hamm_dist_thr, check_orientation, 1, 0};
     return run_projection(curr, q, curr_occupied, pp, matched_query, nullptr, num_matches, device);
 }
 
 int ovs_match_by_sim3_transform(const ovs_frame_view* keyfrm, const ovs_proj_queries* q,
                                 const uint8_t* keyfrm_occupied, float margin,
                                 int32_t* matched_query, uint32_t* num_matches, int device) {
-    proj_params pp{kSim3, margin, OVS_DIR_NONE, 0, 0.0f, kThrLow, 0};
+    proj_params pp{kSim3, margin, OVS_DIR_NONE, 0, 0.0f, kThrLow, 0, 1, 0};
     return run_projection(keyfrm, q, keyfrm_occupied, pp, matched_query, nullptr, num_matches, device);
 }
 
 int ovs_match_keyframe_one_way(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, float margin,
                                int32_t* best_idx_of_query, int device) {
-    proj_params pp{kOneWay, margin, OVS_DIR_NONE, 0, 0.0f, kThrHigh, 0};
+    proj_params pp{kOneWay, margin, OVS_DIR_NONE, 0, 0.0f, kThrHigh, 0, 1, 0};
     return run_projection(keyfrm, q, nullptr, pp, nullptr, best_idx_of_query, nullptr, device);
 }
 
@@ -1204,6 +1471,158 @@ int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, 
         }
     }
     *num_matches = num;
+    return OVS_OK;
+}
+
+int ovs_brute_force_match(const uint8_t* descs_1, const float* angles_1, int n1,
+                          const uint8_t* descs_2, const float* angles_2, const uint8_t* valid_2, int n2,
+                          float lowe_ratio, int check_orientation,
+                          int32_t* matches, uint32_t* num_matches, int device) {
+    // robust::brute_force_match (robust.cc:209-315): queries = keyframe keypoints with a valid
+    // landmark in index order, candidates = all frame keypoints in index order
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && !descs_1) || (n2 > 0 && !descs_2) || !matches || !num_matches
+        || (check_orientation && ((n1 > 0 && !angles_1) || (n2 > 0 && !angles_2)))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    std::vector<u32> entries(n1), q_src, lo, hi;
+    for (int i = 0; i < n1; ++i) {
+        entries[i] = static_cast<u32>(i);
+    }
+    std::vector<uint8_t> qd;
+    std::vector<float> qa;
+    for (int i = 0; i < n2; ++i) {
+        if (valid_2 && !valid_2[i]) {
+            continue;
+        }
+        q_src.push_back(static_cast<u32>(i));
+        lo.push_back(0);
+        hi.push_back(static_cast<u32>(n1));
+        qd.insert(qd.end(), descs_2 + 32 * static_cast<size_t>(i), descs_2 + 32 * static_cast<size_t>(i) + 32);
+        qa.push_back(angles_2 ? angles_2[i] : 0.f);
+    }
+    ranged_problem rp;
+    rp.cand_descs = descs_1;
+    rp.cand_angles = angles_1;
+    rp.n_cand = n1;
+    rp.entry_idx = entries.data();
+    rp.n_entries = n1;
+    rp.q_descs = qd.data();
+    rp.q_angles = qa.data();
+    rp.q_lo = lo.data();
+    rp.q_hi = hi.data();
+    rp.nq = static_cast<int>(q_src.size());
+    rp.lowe = lowe_ratio;
+    rp.check_orientation = check_orientation;
+    rp.angle_sign = -1; // keypts_1[best].angle - keypts_2[idx_2].angle, robust.cc:288-289
+    std::vector<int32_t> matched(n1, -1);
+    int rc = run_ranged(rp, matched.data(), nullptr, num_matches, device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    unsigned k = 0;
+    for (int i = 0; i < n1; ++i) {
+        if (0 <= matched[i]) {
+            matches[2 * k] = i;
+            matches[2 * k + 1] = static_cast<int32_t>(q_src[matched[i]]);
+            ++k;
+        }
+    }
+    return OVS_OK;
+}
+
+int ovs_bow_match_frame_and_keyframe(const ovs_bow_feat_vec* kf_vec, const uint8_t* kf_descs,
+                                     const float* kf_angles, const uint8_t* valid_kf, int n_kf,
+                                     const ovs_bow_feat_vec* frm_vec, const uint8_t* frm_descs,
+                                     const float* frm_angles, int n_frm,
+                                     float lowe_ratio, int check_orientation,
+                                     int32_t* matched_kf_idx_in_frm, uint32_t* num_matches, int device) {
+    int rc;
+    if ((rc = validate_bow(kf_vec)) != OVS_OK || (rc = validate_bow(frm_vec)) != OVS_OK) {
+        return rc;
+    }
+    if (n_kf < 0 || n_frm < 0 || !matched_kf_idx_in_frm || !num_matches || (n_kf > 0 && !kf_descs) || (n_frm > 0 && !frm_descs)
+        || (check_orientation && ((n_kf > 0 && !kf_angles) || (n_frm > 0 && !frm_angles)))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    bow_queries bq;
+    if ((rc = build_bow_queries(kf_vec, kf_descs, kf_angles, valid_kf, n_kf, frm_vec, n_frm, bq)) != OVS_OK) {
+        return rc;
+    }
+    ranged_problem rp;
+    rp.cand_descs = frm_descs;
+    rp.cand_angles = frm_angles;
+    rp.n_cand = n_frm;
+    rp.entry_idx = frm_vec->indices;
+    rp.n_entries = frm_vec->num_nodes ? static_cast<int>(frm_vec->offsets[frm_vec->num_nodes]) : 0;
+    rp.q_descs = bq.descs.data();
+    rp.q_angles = bq.angles.data();
+    rp.q_lo = bq.lo.data();
+    rp.q_hi = bq.hi.data();
+    rp.nq = static_cast<int>(bq.q_src.size());
+    rp.lowe = lowe_ratio;
+    rp.check_orientation = check_orientation;
+    rp.angle_sign = 1; // keyfrm angle - frame angle, bow_tree.cc:92-93
+    std::vector<int32_t> matched(n_frm, -1);
+    if ((rc = run_ranged(rp, matched.data(), nullptr, num_matches, device)) != OVS_OK) {
+        return rc;
+    }
+    for (int i = 0; i < n_frm; ++i) {
+        matched_kf_idx_in_frm[i] = 0 <= matched[i] ? static_cast<int32_t>(bq.q_src[matched[i]]) : -1;
+    }
+    return OVS_OK;
+}
+
+int ovs_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1, const float* angles_1,
+                            const uint8_t* valid_1, int n1,
+                            const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2, const float* angles_2,
+                            const uint8_t* valid_2, int n2,
+                            float lowe_ratio, int check_orientation,
+                            int32_t* matched_idx2_in_kf1, uint32_t* num_matches, int device) {
+    int rc;
+    if ((rc = validate_bow(vec_1)) != OVS_OK || (rc = validate_bow(vec_2)) != OVS_OK) {
+        return rc;
+    }
+    if (n1 < 0 || n2 < 0 || !matched_idx2_in_kf1 || !num_matches || (n1 > 0 && !descs_1) || (n2 > 0 && !descs_2)
+        || (check_orientation && ((n1 > 0 && !angles_1) || (n2 > 0 && !angles_2)))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    bow_queries bq;
+    if ((rc = build_bow_queries(vec_1, descs_1, angles_1, valid_1, n1, vec_2, n2, bq)) != OVS_OK) {
+        return rc;
+    }
+    std::vector<uint8_t> occupied;
+    if (valid_2) {
+        occupied.resize(n2);
+        for (int i = 0; i < n2; ++i) {
+            occupied[i] = valid_2[i] ? 0 : 1; // keyframe-2 keypoints without a usable landmark are skipped
+        }
+    }
+    ranged_problem rp;
+    rp.cand_descs = descs_2;
+    rp.cand_angles = angles_2;
+    rp.n_cand = n2;
+    rp.cand_occupied = valid_2 ? occupied.data() : nullptr;
+    rp.entry_idx = vec_2->indices;
+    rp.n_entries = vec_2->num_nodes ? static_cast<int>(vec_2->offsets[vec_2->num_nodes]) : 0;
+    rp.q_descs = bq.descs.data();
+    rp.q_angles = bq.angles.data();
+    rp.q_lo = bq.lo.data();
+    rp.q_hi = bq.hi.data();
+    rp.nq = static_cast<int>(bq.q_src.size());
+    rp.lowe = lowe_ratio;
+    rp.check_orientation = check_orientation;
+    rp.angle_sign = 1;       // keyframe-1 angle - keyframe-2 angle, bow_tree.cc:220-221
+    rp.per_query_output = 1; // the rotation check clears matched_lms_in_keyfrm_1[idx_1]
+    std::vector<int32_t> acc(bq.q_src.size(), -1);
+    if ((rc = run_ranged(rp, nullptr, acc.data(), num_matches, device)) != OVS_OK) {
+        return rc;
+    }
+    std::fill(matched_idx2_in_kf1, matched_idx2_in_kf1 + n1, -1);
+    for (size_t q = 0; q < bq.q_src.size(); ++q) {
+        if (0 <= acc[q]) {
+            matched_idx2_in_kf1[bq.q_src[q]] = acc[q];
+        }
+    }
     return OVS_OK;
 }
 
@@ -1258,7 +1677,7 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
     auto* d_prob = cv.take<proj_problem>(F);
     OVS_HIP(hipMemcpyAsync(d_sf, scale_factors, static_cast<size_t>(num_scale_levels) * 4, hipMemcpyHostToDevice, st));
 
-    proj_params pp{kCurrLast, margin, OVS_DIR_NONE, num_scale_levels, 0.0f, kThrHigh, check_orientation};
+    proj_params pp{kCurrLast, margin, OVS_DIR_NONE, num_scale_levels, 0.0f, kThrHigh, check_orientation, 1, 0};
     OVS_LAUNCH("k_batch_setup", k_batch_setup, dim3((cap + 255) / 256, n_frames), dim3(256), 0, st,
                d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, num_scale_levels,
                d_cell_start, d_entry, d_gdesc, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,

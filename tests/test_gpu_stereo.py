@@ -1,0 +1,189 @@
+"""GPU parity of match::stereo::compute and robust::match_for_triangulation against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from openvslam_amd import _abi as A
+from openvslam_amd import _lib, synth
+from openvslam_amd.feature import orb_extractor, orb_params
+
+pytestmark = pytest.mark.gpu
+
+# EuRoC stereo configuration (example/euroc/EuRoC_stereo.yaml): fx 435.2, fx * baseline 47.906
+FX, FXB = 435.2046959714599, 47.90639384423901
+
+
+def _views(levels):
+    arr = (A.ImageView * len(levels))()
+    keep = []
+    for i, im in enumerate(levels):
+        im = np.ascontiguousarray(im)
+        keep.append(im)
+        arr[i].data = A.ptr(im, A.u8p)
+        arr[i].width, arr[i].height, arr[i].stride = im.shape[1], im.shape[0], im.shape[1]
+    return arr, keep
+
+
+def _same_float(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,n,seed", [(752, 480, 1000, 3), (640, 480, 1500, 4)])
+def test_stereo_compute_matches_oracle(w, h, n, seed):
+    left, right, disps, band_h = synth.make_stereo_pair(w, h, seed=seed)
+    ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=n), oracle.OrbExtractor(max_num_keypts=n)
+    kl, dl = ref_l.extract(left)
+    kr, dr = ref_r.extract(right)
+    lv = [ref_l.pyramid_level(i) for i in range(8)]
+    rv = [ref_r.pyramid_level(i) for i in range(8)]
+    la, keep_l = _views(lv)
+    ra, keep_r = _views(rv)
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    isf = oracle.scale_table("inv_scale_factors", 8, 1.2)
+    true_baseline = np.float32(FXB / FX)
+    res = []
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        xr = np.full(len(kl), 7.0, dtype=np.float32)
+        dep = np.full(len(kl), 7.0, dtype=np.float32)
+        rc = getattr(lib_, prefix + "stereo_compute")(la, ra, 8, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr),
+                                                      A.ptr(dl, A.u8p), A.ptr(dr, A.u8p), A.ptr(sf, A.f32p), A.ptr(isf, A.f32p),
+                                                      np.float32(FXB), true_baseline, A.ptr(xr, A.f32p), A.ptr(dep, A.f32p), *extra)
+        assert rc == 0
+        res.append((xr, dep))
+    assert _same_float(res[0][0], res[1][0]), "stereo_x_right differs"
+    assert _same_float(res[0][1], res[1][1]), "depths differ"
+    xr, dep = res[0]
+    ok = xr >= 0
+    assert ok.sum() > len(kl) // 5
+    # the recovered disparities follow the banded ground truth
+    band = np.minimum((kl["y"][ok] // band_h).astype(int), len(disps) - 1)
+    err = np.abs((kl["x"][ok] - xr[ok]) - disps[band])
+    assert np.median(err) < 1.0
+
+
+def test_stereo_compute_dev_matches_oracle():
+    w, h, n = 752, 480, 1000
+    dev = torch.device("cuda", 0)
+    left, right, _, _ = synth.make_stereo_pair(w, h, seed=9)
+    exts = [orb_extractor(orb_params(max_num_keypts=n), device=0) for _ in range(2)]
+    cap = exts[0].keypoint_capacity(w, h)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bufs = []
+    for ext, img in zip(exts, (left, right)):
+        d_img = torch.from_numpy(img).to(dev)
+        kps = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ext.extract_batch_dev(d_img.data_ptr(), 1, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, stream)
+        bufs.append((d_img, kps, desc, cnt))
+    xr = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    dep = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    true_baseline = np.float32(FXB / FX)
+    _lib.check(_lib.lib().ovs_stereo_compute_dev(exts[0]._h, 0, exts[1]._h, 0,
+                                                 bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr(),
+                                                 bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), bufs[1][3].data_ptr(), cap,
+                                                 np.float32(FXB), true_baseline, xr.data_ptr(), dep.data_ptr(), 0, stream))
+    torch.cuda.synchronize(dev)
+    nl = int(bufs[0][3].item())
+    ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=n), oracle.OrbExtractor(max_num_keypts=n)
+    kl, dl = ref_l.extract(left)
+    kr, dr = ref_r.extract(right)
+    assert nl == len(kl)
+    la, keep_l = _views([ref_l.pyramid_level(i) for i in range(8)])
+    ra, keep_r = _views([ref_r.pyramid_level(i) for i in range(8)])
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    isf = oracle.scale_table("inv_scale_factors", 8, 1.2)
+    rxr = np.zeros(len(kl), dtype=np.float32)
+    rdep = np.zeros(len(kl), dtype=np.float32)
+    oracle.check(oracle.lib().ovo_stereo_compute(la, ra, 8, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr), A.ptr(dl, A.u8p), A.ptr(dr, A.u8p),
+                                                 A.ptr(sf, A.f32p), A.ptr(isf, A.f32p), np.float32(FXB), true_baseline,
+                                                 A.ptr(rxr, A.f32p), A.ptr(rdep, A.f32p)))
+    assert _same_float(xr.cpu().numpy()[:nl], rxr)
+    assert _same_float(dep.cpu().numpy()[:nl], rdep)
+    assert (rxr >= 0).sum() > 100
+
+
+def test_stereo_out_of_range_row_is_reported():
+    img = np.zeros((64, 64), dtype=np.uint8)
+    la, k1 = _views([img])
+    ra, k2 = _views([img])
+    kp = np.zeros(1, dtype=A.KEYPOINT_DTYPE)
+    kp["x"], kp["y"] = 30, 63.5  # row list spans rows 61..66 -> outside of the 64-row image
+    d = np.zeros((1, 32), dtype=np.uint8)
+    sf = np.ones(1, dtype=np.float32)
+    out = np.zeros(1, dtype=np.float32)
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        rc = getattr(lib_, prefix + "stereo_compute")(la, ra, 1, A.ptr(kp, A.kpp), 1, A.ptr(kp, A.kpp), 1, A.ptr(d, A.u8p), A.ptr(d, A.u8p),
+                                                      A.ptr(sf, A.f32p), A.ptr(sf, A.f32p), 40.0, 0.1, A.ptr(out, A.f32p), A.ptr(out, A.f32p), *extra)
+        assert rc == A.OVS_ERR_OUT_OF_RANGE
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+@pytest.mark.parametrize("seed,n,words,check", [(1, 1500, 120, 1), (2, 800, 20, 0)])
+def test_match_for_triangulation(seed, n, words, check):
+    rng = np.random.default_rng(seed)
+    # two views of the same random points: camera 2 = R * camera 1 + t
+    pts1 = np.column_stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 20, n)])
+    ang = 0.05
+    R21 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t21 = np.array([0.4, 0.02, 0.05])
+    pts2 = pts1 @ R21.T + t21
+    order2 = rng.permutation(n)
+    b1 = _unit(pts1)
+    b2 = _unit(pts2[order2] + rng.normal(0, 0.002, (n, 3)))
+    # E_12 with x1^T E_12 x2 = 0: x1 = R12 x2 + t12
+    R12, t12 = R21.T, -R21.T @ t21
+    tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+    E12 = np.ascontiguousarray(tx @ R12)
+    epipole_in_2 = _unit(t21[None, :])[0].copy()  # camera centre 1 seen from camera 2
+    word = rng.integers(0, words, n)
+    centres = rng.integers(0, 256, (words, 32), dtype=np.uint8)
+    base = centres[word].copy()
+    for i in range(n):
+        for b in rng.choice(256, 40, replace=False):
+            base[i, b >> 3] ^= np.uint8(1 << (b & 7))
+
+    def flip(d, k):
+        d = d.copy()
+        for i in range(len(d)):
+            for b in rng.choice(256, rng.integers(0, k + 1), replace=False):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+
+    d1 = flip(base, 10)
+    d2 = flip(base[order2], 10)
+    k1 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k2 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k1["octave"] = rng.integers(0, 8, n)
+    k1["angle"] = rng.uniform(0, 360, n)
+    k2["angle"] = (k1["angle"][order2] + rng.normal(0, 6, n)) % 360
+    v1, v2 = {}, {}
+    for i in rng.permutation(n):
+        v1.setdefault(int(word[i]), []).append(int(i))
+    for j in rng.permutation(n):
+        v2.setdefault(int(word[order2[j]]), []).append(int(j))
+    fv1, fv2 = A.make_bow_feat_vec(v1), A.make_bow_feat_vec(v2)
+    has1 = (rng.random(n) < 0.3).astype(np.uint8)
+    has2 = (rng.random(n) < 0.3).astype(np.uint8)
+    sxr1 = np.where(rng.random(n) < 0.2, 10.0, -1.0).astype(np.float32)
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    b1c, b2c = np.ascontiguousarray(b1), np.ascontiguousarray(b2)
+    res = []
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        pairs = np.zeros((n, 2), dtype=np.uint32)
+        num = C.c_uint32(0)
+        rc = getattr(lib_, prefix + "match_for_triangulation")(fv1.ref(), A.ptr(d1, A.u8p), A.ptr(k1, A.kpp), A.ptr(b1c, A.f64p), A.ptr(sxr1, A.f32p), A.ptr(has1, A.u8p), n,
+                                                               fv2.ref(), A.ptr(d2, A.u8p), A.ptr(k2, A.kpp), A.ptr(b2c, A.f64p), None, A.ptr(has2, A.u8p), n,
+                                                               A.ptr(E12, A.f64p), A.ptr(epipole_in_2, A.f64p), A.ptr(sf, A.f32p), 8, check,
+                                                               A.ptr(pairs, A.u32p), C.byref(num), *extra)
+        assert rc == 0
+        res.append((pairs[:num.value].copy(), num.value))
+    assert res[0][1] == res[1][1]
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] > n // 20
