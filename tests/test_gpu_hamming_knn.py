@@ -1,0 +1,158 @@
+"""GPU parity of the descriptor-distance entry points, the grid window query and the sharded
+top-2 database search (bit-exact against the CPU oracle)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from openvslam_amd import _abi as A
+from openvslam_amd import _lib, match
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hamming_known_answers_on_device():
+    # test/openvslam/match/base.cc of the reference: equal -> 0, complement -> 256, half -> 128
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 0xFF, np.uint8)
+    half = np.array([0x0F] * 32, np.uint8)
+    assert match.compute_descriptor_distance_32(z, z) == 0
+    assert match.compute_descriptor_distance_32(z, f) == 256
+    assert match.compute_descriptor_distance_32(f, half) == 128
+    assert match.compute_descriptor_distance_32(z, half) == 128
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 4097, 100000])
+def test_hamming_pairs(n):
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    got = np.zeros(n, np.uint32)
+    want = np.zeros(n, np.uint32)
+    _lib.check(_lib.lib().ovs_hamming_pairs(A.ptr(a, A.u8p), A.ptr(b, A.u8p), n, A.ptr(got, A.u32p), 0))
+    oracle.check(oracle.lib().ovo_hamming_pairs(A.ptr(a, A.u8p), A.ptr(b, A.u8p), n, A.ptr(want, A.u32p)))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("na,nb", [(1, 1), (7, 300), (257, 129), (2000, 2100)])
+def test_hamming_matrix(na, nb):
+    rng = np.random.default_rng(na * 7 + nb)
+    a = rng.integers(0, 256, (na, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, (nb, 32), dtype=np.uint8)
+    got = match.descriptor_distance_matrix(a, b)
+    want = np.zeros((na, nb), np.uint16)
+    oracle.check(oracle.lib().ovo_hamming_matrix(A.ptr(a, A.u8p), na, A.ptr(b, A.u8p), nb, A.ptr(want, A.u16p)))
+    assert np.array_equal(got, want)
+
+
+def test_unaligned_descriptor_buffers():
+    """Caller buffers only need byte alignment on the host side (they are staged)."""
+    rng = np.random.default_rng(3)
+    raw = rng.integers(0, 256, 32 * 100 + 3, dtype=np.uint8)
+    a = raw[3:].reshape(100, 32)
+    b = np.ascontiguousarray(a[::-1])
+    got = np.zeros(100, np.uint32)
+    want = np.zeros(100, np.uint32)
+    _lib.check(_lib.lib().ovs_hamming_pairs(A.ptr(a, A.u8p), A.ptr(b, A.u8p), 100, A.ptr(got, A.u32p), 0))
+    oracle.check(oracle.lib().ovo_hamming_pairs(A.ptr(np.ascontiguousarray(a), A.u8p), A.ptr(b, A.u8p), 100, A.ptr(want, A.u32p)))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed,n,nq", [(1, 2000, 500), (2, 30, 64), (3, 0, 5), (4, 5000, 1)])
+def test_get_keypoints_in_cell(seed, n, nq):
+    rng = np.random.default_rng(seed)
+    kps = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 1241, n)
+    kps["y"] = rng.uniform(0, 376, n)
+    kps["octave"] = rng.integers(0, 8, n)
+    desc = np.zeros((n, 32), np.uint8)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    view = A.make_frame_view(kps, desc, sf, A.make_grid(0.0, 0.0, 1241.0, 376.0))
+    xy = np.stack([rng.uniform(-50, 1300, nq), rng.uniform(-50, 420, nq)], axis=1).astype(np.float32)
+    margin = rng.uniform(1, 80, nq).astype(np.float32)
+    lo = rng.integers(-1, 5, nq).astype(np.int32)
+    hi = np.where(rng.random(nq) < 0.3, -1, lo + rng.integers(0, 4, nq)).astype(np.int32)
+    cap = 400000
+    res = []
+    for lib_, pre, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        idx = np.zeros(cap, np.uint32)
+        off = np.zeros(nq + 1, np.uint32)
+        rc = getattr(lib_, pre + "get_keypoints_in_cell")(view.ref(), nq, A.ptr(xy, A.f32p), A.ptr(margin, A.f32p), A.ptr(lo, A.i32p),
+                                                        A.ptr(hi, A.i32p), A.ptr(idx, A.u32p), cap, A.ptr(off, A.u32p), *extra)
+        assert rc == 0
+        res.append((off, idx[:off[-1]].copy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+    if n >= 2000:
+        assert res[0][0][-1] > 1000
+
+
+def test_get_keypoints_in_cell_capacity_error():
+    n = 500
+    kps = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = 100.0, 100.0
+    view = A.make_frame_view(kps, np.zeros((n, 32), np.uint8), np.ones(8, np.float32), A.make_grid(0.0, 0.0, 640.0, 480.0))
+    xy = np.array([[100.0, 100.0]], np.float32)
+    margin = np.array([5.0], np.float32)
+    lo = np.array([-1], np.int32)
+    idx = np.zeros(10, np.uint32)
+    off = np.zeros(2, np.uint32)
+    rc = _lib.lib().ovs_get_keypoints_in_cell(view.ref(), 1, A.ptr(xy, A.f32p), A.ptr(margin, A.f32p), A.ptr(lo, A.i32p), A.ptr(lo, A.i32p),
+                                              A.ptr(idx, A.u32p), 10, A.ptr(off, A.u32p), 0)
+    assert rc == A.OVS_ERR_CAPACITY
+
+
+def db_search(db, first, q):
+    h = C.c_void_p()
+    L = _lib.lib()
+    _lib.check(L.ovs_desc_db_create(0, C.byref(h)))
+    try:
+        _lib.check(L.ovs_desc_db_upload(h, A.ptr(db, A.u8p), len(db), first))
+        out = np.zeros(len(q), dtype=A.KNN2_DTYPE)
+        _lib.check(L.ovs_desc_db_search(h, A.ptr(q, A.u8p), len(q), A.ptr(out, A.knn2p)))
+    finally:
+        L.ovs_desc_db_destroy(h)
+    return out
+
+
+def oracle_search(db, first, q):
+    out = np.zeros(len(q), dtype=A.KNN2_DTYPE)
+    oracle.check(oracle.lib().ovo_knn2_search(A.ptr(db, A.u8p), len(db), first, A.ptr(q, A.u8p), len(q), A.ptr(out, A.knn2p)))
+    return out
+
+
+@pytest.mark.parametrize("seed,rows,nq", [(1, 100000, 300), (2, 4096, 64), (3, 4097, 65), (4, 1, 10), (5, 0, 10), (6, 50000, 1)])
+def test_desc_db_search(seed, rows, nq):
+    rng = np.random.default_rng(seed)
+    # few distinct byte values -> many equal distances, so the lowest-row rule is exercised
+    db = rng.integers(0, 4, (rows, 32), dtype=np.uint8)
+    q = rng.integers(0, 4, (nq, 32), dtype=np.uint8)
+    if rows > 10:
+        db[rows - 1] = db[0]
+        q[0] = db[0]
+    got = db_search(db, 12345, q)
+    want = oracle_search(db, 12345, q)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_sharded_search_equals_whole_database():
+    """Four shards searched one after another on this GPU, merged on the host and on the device,
+    equal the scan of the whole database."""
+    import torch
+    from openvslam_amd import dist as ovd
+    rng = np.random.default_rng(11)
+    db = rng.integers(0, 8, (40001, 32), dtype=np.uint8)
+    q = rng.integers(0, 8, (513, 32), dtype=np.uint8)
+    lists = []
+    for r in range(4):
+        first, count = ovd.shard_rows(len(db), 4, r)
+        lists.append(db_search(np.ascontiguousarray(db[first:first + count]), first, q))
+    lists = np.stack(lists)
+    want = oracle_search(db, 0, q)
+    assert ovd.merge_topk_host(lists, 4, len(q)).tobytes() == want.tobytes()
+    d_lists = torch.from_numpy(lists.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.zeros(len(q) * 24, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.lib().ovs_knn2_merge_dev(d_lists.data_ptr(), 4, len(q), d_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().tobytes() == want.tobytes()
