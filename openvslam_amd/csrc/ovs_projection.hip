@@ -806,6 +806,8 @@ __global__ __launch_bounds__(256) void k_window_list(frame_dev f, int nq, const 
     c.max_level = max_level ? max_level[qi] : -1;
     c.ugate = false;
     c.stereo_gate = false;
+    c.ranged = false;
+    c.lo = c.hi = 0;
     c.xr = 0;
     c.sl = 0;
     u32 written = 0;

@@ -84,7 +84,7 @@ def test_get_keypoints_in_cell(seed, n, nq):
         res.append((off, idx[:off[-1]].copy()))
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1])
-    if n >= 2000:
+    if n >= 2000 and nq >= 500:
         assert res[0][0][-1] > 1000
 
 

@@ -54,15 +54,16 @@ def test_projection_and_robust_mirrors_on_a_sequence():
     assert num > 300
     pairs = match.robust(0.75, True).brute_force_match(d1, k1["angle"], d0, k0["angle"])
     wp = np.zeros((len(k1), 2), np.int32)
-    oracle.check(oracle.lib().ovo_brute_force_match(A.ptr(d1, A.u8p), A.ptr(np.ascontiguousarray(k1["angle"]), A.f32p), len(k1),
-                                                    A.ptr(d0, A.u8p), A.ptr(np.ascontiguousarray(k0["angle"]), A.f32p), None, len(k0),
+    a1, a0 = np.ascontiguousarray(k1["angle"]), np.ascontiguousarray(k0["angle"])  # kept alive across the call
+    oracle.check(oracle.lib().ovo_brute_force_match(A.ptr(d1, A.u8p), A.ptr(a1, A.f32p), len(k1),
+                                                    A.ptr(d0, A.u8p), A.ptr(a0, A.f32p), None, len(k0),
                                                     np.float32(0.75), 1, A.ptr(wp, A.i32p), C.byref(wn)))
     assert np.array_equal(pairs, wp[:wn.value])
     assert len(pairs) > 100
 
 
 def test_stereo_mirror():
-    left, right = synth.make_stereo_pair(640, 480, seed=3)
+    left, right, _, _ = synth.make_stereo_pair(640, 480, seed=3)
     el, er = orb_extractor(orb_params(max_num_keypts=800)), orb_extractor(orb_params(max_num_keypts=800))
     kl, dl = el.extract(left)
     kr, dr = er.extract(right)
