@@ -513,9 +513,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 
 // -------------------------------------------------------------------------------------------------
 // 7x7 Gaussian blur, sigma 2, BORDER_REFLECT_101, 8-bit: separable integer kernel
-// k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact int32 row pass, column pass
-// (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).  64 x 32 output tile per workgroup,
-// source tile with a 3-px halo and the row-pass result (<= 65535, kept as u16) staged in LDS.
+// k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact integer row pass, column pass
+// (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect101(int p, int len) {
     if ((unsigned)p < (unsigned)len) {
@@ -535,16 +534,240 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
-constexpr int kBlurRows = 8; // output rows per thread
+constexpr int kBlurRows = 64;  // output rows per wave tile
+constexpr int kBlurCols = 256; // output columns per wave tile (four per lane)
 
-// One thread produces a strip of 4 x kBlurRows output pixels: it walks kBlurRows + 6 input rows,
-// reads the 10 source bytes of each as three dwords (the neighbouring strips' reads are the same
-// lines, served by the vector cache), keeps the last seven row-pass results in registers and emits
-// one dword per output row.  No LDS and no barrier; strips at the left / right image edge take a
-// byte path with reflected indices.
+// The blur is the exact integer double sum  out = min((sum_j sum_i k[j] k[i] p[y+j][x+i] + 2^15) >> 16, 255):
+// the row pass never rounds (<= 255 * 257 = 65535), so the passes may run in either order and
+// on any grouping of taps.  One wavefront owns a tile of 256 columns x 64 rows and walks down
+// the rows with no LDS and no barrier:
+//   * row pass on raw bytes: a lane holds the four bytes of its columns (C) and gets the dwords of
+//     its left / right neighbours (L, R) by DPP wave shifts (lanes 0 and 63 load theirs); the
+//     seven-byte windows are cut with v_alignbyte and reduced with v_dot4_u32_u8 (two per pixel);
+//   * two consecutive row-pass results are packed as u16 pairs, so the column pass is four
+//     v_dot2_u32_u16 per pixel; the accumulator starts at 0xFF008000 and every dot saturates, which
+//     makes byte 2 of the result the rounded, 255-clamped output with no extra instruction;
+//   * all source bytes are fetched through per-lane offsets that already contain the
+//     BORDER_REFLECT_101 column mapping, so edges, odd strides and unaligned rows need no special
+//     path (rows are reflected in scalar code).
+__device__ __forceinline__ u32 dpp_from_left(u32 own, u32 edge) {
+    // lane i receives lane i - 1's value; lane 0 keeps `edge`
+    return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)own, 0x138, 0xf, 0xf, false); // wave_shr:1
+}
+__device__ __forceinline__ u32 dpp_from_right(u32 own, u32 edge) {
+    // lane i receives lane i + 1's value; lane 63 keeps `edge`
+    return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)own, 0x130, 0xf, 0xf, false); // wave_shl:1
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32 udot2_sat(u32 a, u32 w, u32 acc) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, w), acc, true);
+}
+
+struct blur_row {
+    u32 h[4]; // row-pass results of the lane's four columns
+};
+
+// single reflection, valid for -len < p < 2 * len - 1
+__device__ __forceinline__ int reflect101_near(int p, int len) {
+    p = p < 0 ? -p : p;
+    return p >= len ? 2 * len - 2 - p : p;
+}
+
+__device__ __forceinline__ u32 load_quad(__amdgpu_buffer_rsrc_t plane, const u32 (&off)[4], u32 row_off) {
+    const u32 b0 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[0], row_off, 0);
+    const u32 b1 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[1], row_off, 0);
+    const u32 b2 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[2], row_off, 0);
+    const u32 b3 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[3], row_off, 0);
+    return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+}
+
+// Per-lane, per-tile constants of the row pass.
+struct blur_lane {
+    u32 off[4];   // reflected byte offsets of the lane's columns (byte path)
+    u32 eoff[4];  // the same for the halo dword of lanes 0 / 63
+    u32 voff;     // 4 * lane: dword path
+    bool byte_lane; // the lane's dword touches columns >= w: reflected byte loads
+    bool edge_lane; // lane 0 or 63
+};
+
+// Loads of one source row, issued ahead of their use (the tile loop keeps the next two rows in
+// flight while it computes on the current two).
+struct blur_raw {
+    u32 a0, a1; // dword path (a1 only for unaligned planes)
+    u32 b[4];   // byte path of lanes whose dword touches columns >= w
+    u32 e[4];   // halo dword of lanes 0 / 63
+};
+
+// `row_off` = byte offset of the row from the plane base, `tile_byte` = offset of the first tile
+// column inside the row (both include the base misalignment for caller-owned images).
+template <bool UNALIGNED>
+__device__ __forceinline__ blur_raw blur_row_issue(__amdgpu_buffer_rsrc_t plane, u32 row_off, u32 tile_byte, const blur_lane& ln, bool wave_has_byte_lanes) {
+    blur_raw w;
+    const u32 row_byte = row_off + tile_byte;
+    if (UNALIGNED) {
+        // rows of a caller-owned image start at any byte: two aligned dwords and a byte shift
+        w.a0 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff, row_byte & ~3u, 0);
+        w.a1 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff + 4, row_byte & ~3u, 0);
+    }
+    else {
+        w.a0 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff, row_byte, 0);
+        w.a1 = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        w.b[k] = 0;
+        w.e[k] = 0;
+    }
+    if (wave_has_byte_lanes) {
+        if (ln.byte_lane) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w.b[k] = __builtin_amdgcn_raw_buffer_load_b8(plane, ln.off[k], row_off, 0);
+            }
+        }
+    }
+    if (ln.edge_lane) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w.e[k] = __builtin_amdgcn_raw_buffer_load_b8(plane, ln.eoff[k], row_off, 0);
+        }
+    }
+    return w;
+}
+
+template <bool UNALIGNED>
+__device__ __forceinline__ blur_row blur_row_finish(const blur_raw& w, u32 shift, const blur_lane& ln, bool wave_has_byte_lanes) {
+    // kernel bytes, LSB first: taps 0..3 and taps 4..6
+    constexpr u32 kWa = 18u | (34u << 8) | (49u << 16) | (55u << 24);
+    constexpr u32 kWb = 49u | (34u << 8) | (18u << 16);
+    u32 c = UNALIGNED ? __builtin_amdgcn_alignbyte(w.a1, w.a0, shift) : w.a0;
+    if (wave_has_byte_lanes) {
+        const u32 cb = w.b[0] | (w.b[1] << 8) | (w.b[2] << 16) | (w.b[3] << 24);
+        c = ln.byte_lane ? cb : c;
+    }
+    const u32 e = w.e[0] | (w.e[1] << 8) | (w.e[2] << 16) | (w.e[3] << 24);
+    const u32 l = dpp_from_left(c, e);
+    const u32 r = dpp_from_right(c, e);
+    blur_row out;
+    out.h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 1), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 1), kWa, 0u, false), false);
+    out.h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 2), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 2), kWa, 0u, false), false);
+    out.h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 3), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 3), kWa, 0u, false), false);
+    out.h[3] = __builtin_amdgcn_udot4(r, kWb, __builtin_amdgcn_udot4(c, kWa, 0u, false), false);
+    return out;
+}
+
+// Column pass for one output row from four row pairs q[m][col] = h(row 2m) | h(row 2m + 1) << 16.
+// ODD = false: rows 0..6 of the eight;  ODD = true: rows 1..7.
+template <bool ODD>
+__device__ __forceinline__ u32 blur_col_pass(const u32 (&q0)[4], const u32 (&q1)[4], const u32 (&q2)[4], const u32 (&q3)[4]) {
+    constexpr u32 w0 = ODD ? (18u << 16) : (18u | (34u << 16));
+    constexpr u32 w1 = ODD ? (34u | (49u << 16)) : (49u | (55u << 16));
+    constexpr u32 w2 = ODD ? (55u | (49u << 16)) : (49u | (34u << 16));
+    constexpr u32 w3 = ODD ? (34u | (18u << 16)) : 18u;
+    u32 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        u32 a = udot2_sat(q0[c], w0, 0xFF008000u);
+        a = udot2_sat(q1[c], w1, a);
+        a = udot2_sat(q2[c], w2, a);
+        v[c] = udot2_sat(q3[c], w3, a);
+    }
+    // byte 2 of each accumulator
+    const u32 lo = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u);
+    const u32 hi = __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
+    return lo | hi;
+}
+
+template <bool UNALIGNED>
+__device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* img, u32 pitch, uint8_t* dst, int y0, int cb, int lane) {
+    const int nrows = min(kBlurRows, g.h - y0);
+    // the level plane as a buffer resource based at the 4-byte aligned address at or below its
+    // first byte: loads take (per-lane byte offset, scalar row offset) and need no address
+    // arithmetic; reads outside the plane return 0 instead of faulting
+    const u32 delta = UNALIGNED ? (u32)(reinterpret_cast<uintptr_t>(img) & 3) : 0u;
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img) - delta, 0,
+                                                                           (int)(delta + pitch * (u32)(g.h - 1) + (u32)g.w), 0x00020000);
+    // column indices reflected (BORDER_REFLECT_101) and clamped to the reach of the 7-tap window
+    // beyond the last column
+    const int col = cb + 4 * lane;
+    const int ecol = lane == 0 ? cb - 4 : cb + kBlurCols;
+    blur_lane ln;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ln.off[k] = delta + (u32)reflect101_near(min(col + k, g.w + 2), g.w);
+        ln.eoff[k] = delta + (u32)reflect101_near(min(ecol + k, g.w + 2), g.w);
+    }
+    ln.voff = 4u * (u32)lane;
+    ln.byte_lane = col + 4 > g.w;
+    ln.edge_lane = lane == 0 || lane == 63;
+    const bool wave_has_byte_lanes = cb + kBlurCols > g.w;
+    const bool store_lane = col < g.pitch;
+    const u32 tile_byte = delta + (u32)cb;
+
+    u32 q[4][4];
+    // input row j of the tile is image row y0 - 3 + j; pairs (2m, 2m + 1)
+    u32 ra = (u32)reflect101_near(y0 - 3, g.h) * pitch, rb = (u32)reflect101_near(y0 - 2, g.h) * pitch;
+    blur_raw wa = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
+    blur_raw wb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const u32 sa = (ra + tile_byte) & 3u, sb = (rb + tile_byte) & 3u;
+        ra = (u32)reflect101_near(y0 - 1 + 2 * m, g.h) * pitch;
+        rb = (u32)reflect101_near(y0 + 2 * m, g.h) * pitch;
+        const blur_raw na = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
+        const blur_raw nb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
+        const blur_row a = blur_row_finish<UNALIGNED>(wa, sa, ln, wave_has_byte_lanes);
+        const blur_row b = blur_row_finish<UNALIGNED>(wb, sb, ln, wave_has_byte_lanes);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            q[m][c] = a.h[c] | (b.h[c] << 16);
+        }
+        wa = na;
+        wb = nb;
+    }
+    // here wa / wb hold rows y0 + 3, y0 + 4: the pair the first two output rows still need
+#pragma unroll 1
+    for (int o = 0; o < nrows; o += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int oo = o + 2 * i; // output rows oo, oo + 1 need pairs oo/2 .. oo/2 + 3
+            if (oo < nrows) {
+                const u32 sa = (ra + tile_byte) & 3u, sb = (rb + tile_byte) & 3u;
+                // rows of the next step (reflected, so always inside the plane)
+                ra = (u32)reflect101_near(min(y0 + oo + 5, g.h + 2), g.h) * pitch;
+                rb = (u32)reflect101_near(min(y0 + oo + 6, g.h + 2), g.h) * pitch;
+                const blur_raw na = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
+                const blur_raw nb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
+                const blur_row a = blur_row_finish<UNALIGNED>(wa, sa, ln, wave_has_byte_lanes);
+                const blur_row b = blur_row_finish<UNALIGNED>(wb, sb, ln, wave_has_byte_lanes);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    q[(i + 3) & 3][c] = a.h[c] | (b.h[c] << 16);
+                }
+                const u32 r0 = blur_col_pass<false>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
+                const u32 r1 = blur_col_pass<true>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
+                if (store_lane) {
+                    *reinterpret_cast<u32*>(dst + (long long)oo * g.pitch + col) = r0;
+                    if (oo + 1 < nrows) {
+                        *reinterpret_cast<u32*>(dst + (long long)(oo + 1) * g.pitch + col) = r1;
+                    }
+                }
+                wa = na;
+                wb = nb;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur) {
     const int frame = blockIdx.y;
-    int t = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (t >= p.total_blur_tiles) {
+        return;
+    }
     int level = 0;
 #pragma unroll 1
     for (int l = 1; l < p.num_levels; ++l) {
@@ -553,56 +776,19 @@ __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t
         }
     }
     const level_geom& g = p.lv[level];
-    const int strips = (g.w + 3) >> 2;
-    const int item = (t - g.blur_tile_base) * 256 + threadIdx.x;
-    const int rg = item / strips, strip = item - rg * strips;
-    const int y0 = rg * kBlurRows, x = strip * 4;
-    if (y0 >= g.h) {
-        return;
+    const int rel = t - g.blur_tile_base;
+    const int ty = rel / g.blur_tiles_x, tx = rel - ty * g.blur_tiles_x;
+    const int y0 = ty * kBlurRows, cb = tx * kBlurCols;
+    long long pitch64;
+    const uint8_t* img = level_ptr(p, s, frame, level, pitch64);
+    uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)y0 * g.pitch;
+    // library planes are 256-byte aligned with a pitch that is a multiple of 64; a caller's
+    // level-0 image may start anywhere and have any stride
+    if (level == 0 && (((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch64) & 3) != 0)) {
+        blur_tile<true>(g, img, (u32)pitch64, dst, y0, cb, lane);
     }
-    long long pitch;
-    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off;
-    const bool interior = x >= 4 && x + 8 <= g.w;
-
-    int rp[7][4];
-#pragma unroll
-    for (int r = 0; r < kBlurRows + 6; ++r) {
-        const int sy = reflect101(y0 + r - 3, g.h);
-        const uint8_t* row = img + (long long)sy * pitch;
-        int b[10];
-        if (interior) {
-            const u32 d0 = load_u32_unaligned(row + x - 4), d1 = load_u32_unaligned(row + x), d2 = load_u32_unaligned(row + x + 4);
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                b[k] = win_byte(d0, d1, d2, k + 1);
-            }
-        }
-        else {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                b[k] = row[reflect101(x - 3 + k, g.w)];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            rp[r % 7][j] = 18 * (b[j] + b[j + 6]) + 34 * (b[j + 1] + b[j + 5]) + 49 * (b[j + 2] + b[j + 4]) + 55 * b[j + 3];
-        }
-        if (r >= 6) {
-            const int y = y0 + r - 6;
-            if (y < g.h) {
-                u32 packed = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // rows y-3 .. y+3 are slots (r-6) % 7 .. r % 7; the kernel is symmetric
-                    const int v = 18 * (rp[(r - 6) % 7][j] + rp[r % 7][j]) + 34 * (rp[(r - 5) % 7][j] + rp[(r - 1) % 7][j])
-                                  + 49 * (rp[(r - 4) % 7][j] + rp[(r - 2) % 7][j]) + 55 * rp[(r - 3) % 7][j];
-                    const int o = min((v + (1 << 15)) >> 16, 255);
-                    packed |= (u32)o << (8 * j);
-                }
-                *reinterpret_cast<u32*>(dst + (long long)y * g.pitch + x) = packed;
-            }
-        }
+    else {
+        blur_tile<false>(g, img, (u32)pitch64, dst, y0, cb, lane);
     }
 }
 
@@ -1440,9 +1626,9 @@ int build_plan(ovs_orb* h, int width, int height) {
         g.scale = h->scale_factors.at(l);
         g.patch_size = static_cast<float>(static_cast<unsigned int>(31 * h->scale_factors.at(l)));
         g.blur_tile_base = blur_tile_base;
-        g.blur_tiles_x = (((g.w + 3) / 4) * ((g.h + kBlurRows - 1) / kBlurRows) + 255) / 256; // workgroups of 256 strips
-        g.blur_tiles_y = 1;
-        blur_tile_base += g.blur_tiles_x;
+        g.blur_tiles_x = (g.w + kBlurCols - 1) / kBlurCols; // wave tiles of kBlurCols x kBlurRows
+        g.blur_tiles_y = (g.h + kBlurRows - 1) / kBlurRows;
+        blur_tile_base += g.blur_tiles_x * g.blur_tiles_y;
         g.tab_off = tab_off;
         g.area2x = 0;
         if (l >= 1) {
@@ -1749,7 +1935,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     }
     OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(p.total_cells, n_frames), dim3(256), 0, stream,
                p, src, h->slots.as<u32>(), h->cell_counts.as<u32>());
-    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(p.total_blur_tiles, n_frames), dim3(256), 0, stream,
+    OVS_LAUNCH("k_gauss7", k_gauss7, dim3((p.total_blur_tiles + 3) / 4, n_frames), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>());
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand_xy.as<u32>(), h->cand_st.as<u32>(),
