@@ -41,6 +41,7 @@ constexpr int kQtThreads = 512;
 
 typedef unsigned int u32;
 typedef unsigned long long u64;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct level_geom {
     int w, h;
@@ -59,6 +60,7 @@ struct level_geom {
     float patch_size;     // (float)(unsigned)(31 * scale), orb_extractor.cc:380,388
     int tab_off;          // offset of the resize tables of this level in the table buffer
     int area2x;           // cv::resize switches to INTER_AREA for an exact 2x reduction
+    int resize_rows;      // tables fit the row-streaming resize kernel
     int blur_tile_base, blur_tiles_x, blur_tiles_y;
 };
 
@@ -199,6 +201,148 @@ __global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, 
         }
     }
     *reinterpret_cast<u32*>(dst + (long long)dy * g.pitch + dx0) = packed;
+}
+
+// The same arithmetic organised for instruction count: one wavefront owns 256 output columns
+// (four per lane, one dword store) and walks down kResizeRows output rows.  It streams the source
+// rows in order; each source row gets ONE row pass per lane -- an 8-byte window (one 12-byte
+// buffer load, two v_alignbyte), then per pixel a v_perm that drops S[sx] and S[sx + 1] into the
+// two halves of a register and a v_dot2_u32_u16 with the (a0, a1) coefficient pair -- and is used
+// by the (at most two) output rows that reference it.  Selectors and coefficients are per-lane
+// constants read once from the tables; row offsets and the vertical coefficients are scalars.
+// Used when the tables are monotone with 1 <= sy(dy + 1) - sy(dy) <= 2 and every group of four
+// output columns reads at most 8 consecutive source bytes (any scale factor in (1, 2)); other
+// geometries take k_resize_linear.
+constexpr int kResizeRows = 16;
+
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+
+struct resize_lane {
+    u32 sel[4]; // v_perm selectors: byte 0 <- S[sx], byte 2 <- S[min(sx + 1, ws - 1)], bytes 1 and 3 <- 0
+    u32 ab[4];  // a0 | a1 << 16
+    u32 sx0;    // first source column of the lane's window
+};
+
+template <bool UNALIGNED>
+__device__ __forceinline__ u32x3 resize_row_issue(__amdgpu_buffer_rsrc_t plane, u32 row_off, const resize_lane& ln) {
+    if (UNALIGNED) {
+        const u32 t = (row_off & 3u) + ln.sx0;
+        return __builtin_amdgcn_raw_buffer_load_b96(plane, t & ~3u, row_off & ~3u, 0);
+    }
+    return __builtin_amdgcn_raw_buffer_load_b96(plane, ln.sx0 & ~3u, row_off, 0);
+}
+
+// row pass: g[k] = (S[sx_k] * a0_k + S[sx_k + 1] * a1_k) >> 4
+template <bool UNALIGNED>
+__device__ __forceinline__ void resize_row_finish(const u32x3& d, u32 row_off, const resize_lane& ln, u32 (&g)[4]) {
+    const u32 shift = UNALIGNED ? (((row_off & 3u) + ln.sx0) & 3u) : (ln.sx0 & 3u);
+    const u32 lo = __builtin_amdgcn_alignbyte(d.y, d.x, shift);
+    const u32 hi = __builtin_amdgcn_alignbyte(d.z, d.y, shift);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 pair = __builtin_amdgcn_perm(hi, lo, ln.sel[k]);
+        g[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pair), __builtin_bit_cast(u16x2, ln.ab[k]), 0u, false) >> 4;
+    }
+}
+
+// column pass and store of one output row: (((b0 * g0) >> 16) + ((b1 * g1) >> 16) + 2) >> 2
+__device__ __forceinline__ void resize_emit(const u32 (&g0)[4], const u32 (&g1)[4], u32 bb, __amdgpu_buffer_rsrc_t out, u32 out_voff, u32 out_row_off, bool store_lane) {
+    const u32 b0 = bb & 0xFFFFu, b1 = bb >> 16;
+    u32 packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 p0 = __umul24(g0[k], b0), p1 = __umul24(g1[k], b1);
+        const u32 halves = __builtin_amdgcn_perm(p1, p0, 0x07060302u); // (p0 >> 16) | (p1 >> 16) << 16
+        const u32 v = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, halves), (u16x2){1, 1}, 2u, false) >> 2;
+        packed |= v << (8 * k);
+    }
+    if (store_lane) {
+        __builtin_amdgcn_raw_buffer_store_b32(packed, out, out_voff, out_row_off, 0);
+    }
+}
+
+template <bool UNALIGNED>
+__device__ __forceinline__ void resize_tile(const level_geom& g, const level_geom& gs, const uint8_t* src, u32 spitch, uint8_t* dst,
+                                            const int* __restrict__ tabs, int y0, int cb, int lane) {
+    const int w4 = (g.w + 3) & ~3;
+    const int* xofs = tabs + g.tab_off;
+    const int* xab = xofs + w4;
+    const int* yofs = xab + w4;
+    const int* yab = yofs + g.h;
+    const u32 delta = UNALIGNED ? (u32)(reinterpret_cast<uintptr_t>(src) & 3) : 0u;
+    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src) - delta, 0,
+                                                                           (int)((delta + spitch * (u32)(gs.h - 1) + (u32)gs.w + 3u) & ~3u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((u32)g.pitch * (u32)g.h), 0x00020000);
+    const int dx0 = cb + 4 * lane;
+    const bool store_lane = dx0 < w4;
+    const int tx = min(dx0, w4 - 4);
+    const int4 so = *reinterpret_cast<const int4*>(xofs + tx);
+    const int4 sa = *reinterpret_cast<const int4*>(xab + tx);
+    const int sx[4] = {so.x, so.y, so.z, so.w};
+    resize_lane ln;
+    ln.ab[0] = (u32)sa.x; ln.ab[1] = (u32)sa.y; ln.ab[2] = (u32)sa.z; ln.ab[3] = (u32)sa.w;
+    ln.sx0 = (u32)sx[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // table entries past the last column are zero: keep their offsets inside the window
+        const int o = min(max(sx[k] - sx[0], 0), 6);
+        const int o1 = min(max(min(sx[k] + 1, gs.w - 1) - sx[0], 0), 7);
+        ln.sel[k] = 0x0c000c00u | (u32)o | ((u32)o1 << 16);
+    }
+    const int y_end = min(y0 + kResizeRows, g.h);
+    const int last_src = gs.h - 1;
+    int dy = y0;
+    int sy_next = yofs[dy];
+    int r = sy_next; // source rows r, r + 1, ... are streamed; row index clamped when fetched
+    u32 ro_a = delta + (u32)min(r, last_src) * spitch, ro_b = delta + (u32)min(r + 1, last_src) * spitch;
+    u32x3 raw_a = resize_row_issue<UNALIGNED>(plane, ro_a, ln);
+    u32x3 raw_b = resize_row_issue<UNALIGNED>(plane, ro_b, ln);
+    u32 ga[4], gb[4] = {0, 0, 0, 0};
+    const u32 out_voff = (u32)dx0;
+#pragma unroll 1
+    for (;; r += 2) {
+        resize_row_finish<UNALIGNED>(raw_a, ro_a, ln, ga);
+        ro_a = delta + (u32)min(r + 2, last_src) * spitch;
+        raw_a = resize_row_issue<UNALIGNED>(plane, ro_a, ln);
+        if (sy_next + 1 == r) {
+            resize_emit(gb, ga, (u32)yab[dy], out, out_voff, (u32)dy * (u32)g.pitch, store_lane);
+            if (++dy == y_end) {
+                break;
+            }
+            sy_next = yofs[dy];
+        }
+        resize_row_finish<UNALIGNED>(raw_b, ro_b, ln, gb);
+        ro_b = delta + (u32)min(r + 3, last_src) * spitch;
+        raw_b = resize_row_issue<UNALIGNED>(plane, ro_b, ln);
+        if (sy_next == r) {
+            resize_emit(ga, gb, (u32)yab[dy], out, out_voff, (u32)dy * (u32)g.pitch, store_lane);
+            if (++dy == y_end) {
+                break;
+            }
+            sy_next = yofs[dy];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_resize_rows(plan_dev p, image_src s, const int* __restrict__ tabs, int level, int tiles_x, int tiles) {
+    const level_geom& g = p.lv[level];
+    const level_geom& gs = p.lv[level - 1];
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (t >= tiles) {
+        return;
+    }
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    long long spitch;
+    const uint8_t* src = level_ptr(p, s, frame, level - 1, spitch);
+    uint8_t* dst = s.pyr + frame * p.frame_pyr_bytes + g.pyr_off;
+    if (level == 1 && (((reinterpret_cast<uintptr_t>(src) | (uintptr_t)spitch) & 3) != 0)) {
+        resize_tile<true>(g, gs, src, (u32)spitch, dst, tabs, ty * kResizeRows, tx * 256, lane);
+    }
+    else {
+        resize_tile<false>(g, gs, src, (u32)spitch, dst, tabs, ty * kResizeRows, tx * 256, lane);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -559,8 +703,6 @@ __device__ __forceinline__ u32 dpp_from_right(u32 own, u32 edge) {
     return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)own, 0x130, 0xf, 0xf, false); // wave_shl:1
 }
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ u32 udot2_sat(u32 a, u32 w, u32 acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, w), acc, true);
 }
@@ -685,10 +827,12 @@ __device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* im
     const int nrows = min(kBlurRows, g.h - y0);
     // the level plane as a buffer resource based at the 4-byte aligned address at or below its
     // first byte: loads take (per-lane byte offset, scalar row offset) and need no address
-    // arithmetic; reads outside the plane return 0 instead of faulting
+    // arithmetic; reads outside the plane return 0 instead of faulting (the size is rounded up to
+    // whole dwords: a dword that straddles the end would read as 0, and one that holds a valid byte
+    // is always backed by memory)
     const u32 delta = UNALIGNED ? (u32)(reinterpret_cast<uintptr_t>(img) & 3) : 0u;
     const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img) - delta, 0,
-                                                                           (int)(delta + pitch * (u32)(g.h - 1) + (u32)g.w), 0x00020000);
+                                                                           (int)((delta + pitch * (u32)(g.h - 1) + (u32)g.w + 3u) & ~3u), 0x00020000);
     // column indices reflected (BORDER_REFLECT_101) and clamped to the reach of the 7-tap window
     // beyond the last column
     const int col = cb + 4 * lane;
@@ -1545,6 +1689,32 @@ void resize_tables(int ssize, int dsize, bool clamp, int* ofs, int* coef) {
     }
 }
 
+// true when the row-streaming resize kernel applies: every aligned group of four output columns
+// reads at most 8 consecutive source bytes and the source rows advance by one or two per output row
+bool resize_tables_stream(const int* xofs, int dw, const int* yofs, int dh) {
+    for (int d = 0; d + 1 < dw; ++d) {
+        if (xofs[d + 1] < xofs[d]) {
+            return false;
+        }
+    }
+    for (int d0 = 0; d0 < dw; d0 += 4) {
+        const int last = std::min(d0 + 3, dw - 1);
+        if (xofs[last] + 1 - xofs[d0] >= 8) {
+            return false;
+        }
+    }
+    if (dh < 1 || yofs[0] < 0) {
+        return false;
+    }
+    for (int d = 0; d + 1 < dh; ++d) {
+        const int step = yofs[d + 1] - yofs[d];
+        if (step < 1 || step > 2) {
+            return false;
+        }
+    }
+    return true;
+}
+
 bool is_area_fast_2x(int sw, int sh, int dw, int dh) {
     const double scale_x = 1. / (static_cast<double>(dw) / sw);
     const double scale_y = 1. / (static_cast<double>(dh) / sh);
@@ -1639,6 +1809,7 @@ int build_plan(ovs_orb* h, int width, int height) {
             tabs.resize(tab_off + seg, 0);
             resize_tables(gs.w, g.w, true, tabs.data() + tab_off, tabs.data() + tab_off + w4);
             resize_tables(gs.h, g.h, false, tabs.data() + tab_off + 2 * w4, tabs.data() + tab_off + 2 * w4 + g.h);
+            g.resize_rows = (!g.area2x && resize_tables_stream(tabs.data() + tab_off, g.w, tabs.data() + tab_off + 2 * w4, g.h)) ? 1 : 0;
             tab_off += seg;
         }
         p.max_cells = std::max(p.max_cells, g.cells_x * g.cells_y);
@@ -1930,8 +2101,14 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
 
     for (int l = 1; l < p.num_levels; ++l) {
         const level_geom& g = p.lv[l];
-        dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, n_frames), block(64, 4, 1);
-        OVS_LAUNCH("k_resize_linear", k_resize_linear, grid, block, 0, stream, p, src, h->tabs.as<int>(), l);
+        if (g.resize_rows) {
+            const int tiles_x = (g.w + 255) / 256, tiles = tiles_x * ((g.h + kResizeRows - 1) / kResizeRows);
+            OVS_LAUNCH("k_resize_rows", k_resize_rows, dim3((tiles + 3) / 4, n_frames), dim3(256), 0, stream, p, src, h->tabs.as<int>(), l, tiles_x, tiles);
+        }
+        else {
+            dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, n_frames), block(64, 4, 1);
+            OVS_LAUNCH("k_resize_linear", k_resize_linear, grid, block, 0, stream, p, src, h->tabs.as<int>(), l);
+        }
     }
     OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(p.total_cells, n_frames), dim3(256), 0, stream,
                p, src, h->slots.as<u32>(), h->cell_counts.as<u32>());

@@ -69,3 +69,48 @@ def test_batch_extract_and_match(w, h, n_kp, n_frames):
         n = r_counts[f]
         assert np.array_equal(h_matched[f, :n], r_matched[f, :n]), "frame %d matches differ" % f
     assert r_num[1:].min() > n_kp // 10
+
+
+@pytest.mark.parametrize("w,h,base_off,pad", [(641, 479, 1, 0), (1241, 376, 3, 5), (322, 247, 2, 1), (640, 480, 0, 0)])
+def test_unaligned_caller_images(w, h, base_off, pad):
+    """Level-0 images that start at any byte, with any row stride, and end exactly at the end of
+    their allocation: the kernels' aligned-dword and buffer-bounded loads must see every pixel of
+    the last rows and columns (compared plane by plane and keypoint by keypoint)."""
+    dev = torch.device("cuda", 0)
+    n_frames = 2
+    frames = synth.make_sequence(w, h, n_frames, seed=5 + w, dx=2, dy=1)
+    stride = w + pad
+    frame_stride = stride * h + 7
+    # one exactly sized allocation: the last image ends at its last byte
+    total = base_off + frame_stride * (n_frames - 1) + stride * (h - 1) + w
+    buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+    host = np.zeros(total, dtype=np.uint8)
+    for f in range(n_frames):
+        for y in range(h):
+            o = base_off + f * frame_stride + y * stride
+            host[o:o + w] = frames[f, y]
+    buf.copy_(torch.from_numpy(host))
+    ext = orb_extractor(orb_params(max_num_keypts=800), device=0)
+    cap = ext.keypoint_capacity(w, h)
+    kps = torch.zeros((n_frames, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_frames, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ext.extract_batch_dev(buf.data_ptr() + base_off, n_frames, w, h, stride, frame_stride, kps.data_ptr(), desc.data_ptr(),
+                          counts.data_ptr(), cap, stream)
+    torch.cuda.synchronize(dev)
+    h_counts = counts.cpu().numpy()
+    h_kps = kps.cpu().numpy().view(np.uint8).reshape(n_frames, cap, 28).copy().view(A.KEYPOINT_DTYPE).reshape(n_frames, cap)
+    h_desc = desc.cpu().numpy()
+    ref = oracle.OrbExtractor(max_num_keypts=800)
+    for f in range(n_frames):
+        k, d = ref.extract(frames[f])
+        for lvl in range(1, 8):
+            assert np.array_equal(ext.image_pyramid(lvl, frame=f), ref.pyramid_level(lvl)), "frame %d pyramid level %d" % (f, lvl)
+        for lvl in range(8):
+            want = ref.blurred_level(lvl)
+            if want is not None:
+                assert np.array_equal(ext.blurred_level(lvl, frame=f), want), "frame %d blurred level %d" % (f, lvl)
+        assert h_counts[f] == len(k)
+        assert np.array_equal(h_kps[f, :len(k)].view(np.uint8), k.view(np.uint8))
+        assert np.array_equal(h_desc[f, :len(k)], d)
