@@ -43,13 +43,16 @@ MARGIN = 20.0
 LEVEL_PX = [1241 * 376, 1034 * 313, 862 * 261, 718 * 218, 598 * 181, 499 * 151, 416 * 126, 346 * 105]
 A_PX, P_PX, P7_PX = sum(LEVEL_PX), LEVEL_PX[0], LEVEL_PX[-1]
 STAGE_BYTES = {
-    "k_resize_linear": (A_PX - P7_PX) + (A_PX - P_PX),   # read levels 0..6, write levels 1..7
+    "resize": (A_PX - P7_PX) + (A_PX - P_PX),            # read levels 0..6, write levels 1..7
     "k_fast_cells": A_PX,                                # read every level once
     "k_gauss7": 2 * A_PX,                                # read + write every level
-    "k_orient_desc": MAX_KP * (28 + 32),                 # keypoints + descriptors out
+    "k_quadtree": MAX_KP * 28,                           # keypoints out
+    "k_orient_desc": MAX_KP * 32,                        # descriptors out
     "match": 2 * MAX_KP * 32 + MAX_KP * 28,              # two descriptor sets + keypoints in
 }
 PATH_BYTES_PER_FRAME = sum(STAGE_BYTES.values())         # 7 021 539
+STAGE_OF_KERNEL = {"k_resize_rows": "resize", "k_resize_linear": "resize", "k_batch_setup": "match", "k_grid_build": "match",
+                   "k_proj_candidates": "match", "k_proj_resolve": "match"}
 assert PATH_BYTES_PER_FRAME == 7021539
 HBM_PEAK_GBS = 8000.0
 
@@ -105,8 +108,8 @@ class Pipeline:
             MARGIN, 1, self.matched.data_ptr(), self.num_matches.data_ptr(), self.device_index, stream))
 
 
-def cpu_baseline(frames_host, seconds_budget=20.0):
-    """The CPU oracle (restated reference path) on a bounded sample of the same frames, one thread."""
+def _cpu_chunk(frames_host, first, stop, deadline, out, slot):
+    """extract + match of frames [first, stop) with frame first - 1 (or first) as the halo."""
     sys.path.insert(0, str(ROOT / "tests"))
     import oracle
     ext = oracle.OrbExtractor(max_num_keypts=MAX_KP, scale_factor=SCALE, num_levels=LEVELS)
@@ -115,8 +118,7 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
     sf = oracle.scale_table("scale_factors", LEVELS, SCALE)
     prev = None
     done = 0
-    t0 = time.perf_counter()
-    for f in range(len(frames_host)):
+    for f in range(first, stop):
         kps, desc = ext.extract(frames_host[f])
         if prev is not None:
             pk, pd = prev
@@ -129,11 +131,64 @@ def cpu_baseline(frames_host, seconds_budget=20.0):
                                                               A.ptr(matched, A.i32p), C.byref(num)))
             done += 1
         prev = (kps, desc)
-        if time.perf_counter() - t0 > seconds_budget and done >= 4:
+        if time.perf_counter() > deadline and done >= 2:
             break
+    out[slot] = done
+
+
+def cpu_baseline(frames_host, seconds_budget=15.0):
+    """The CPU oracle (restated reference path) on a bounded sample of the same frames: first one
+    thread (the reference's default build has OpenMP off), then frame-parallel over the host cores
+    this process may use (contiguous chunks with a halo frame, as the GPU ranks shard)."""
+    import threading
+    res = [0]
+    t0 = time.perf_counter()
+    _cpu_chunk(frames_host, 0, len(frames_host), t0 + seconds_budget / 3.0, res, 0)
+    single = res[0] / (time.perf_counter() - t0)
+    n_thr = max(1, min(16, len(os.sched_getaffinity(0)), (len(frames_host) - 1) // 4))
+    per = (len(frames_host) - 1) // n_thr
+    res = [0] * n_thr
+    t0 = time.perf_counter()
+    deadline = t0 + 2.0 * seconds_budget / 3.0
+    threads = [threading.Thread(target=_cpu_chunk, args=(frames_host, i * per, i * per + per + 1, deadline, res, i)) for i in range(n_thr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     dt = time.perf_counter() - t0
-    # the first frame only primes the matcher: charge its extraction to the sample
-    return done / dt, done
+    return sum(res) / dt, sum(res), n_thr, single
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs, gfx950 corrections applied by tools/summarize_prof.py)."""
+    import csv
+    path = ROOT / "profiles" / "r1_pmc_per_kernel.csv"
+    if not path.exists():
+        return None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["kernel"] == kernel:
+                try:
+                    return float(row["hbm_read_bytes(=2*FETCH_SIZE*1024)"]) + float(row["hbm_write_bytes(=WRITE_SIZE*1024)"])
+                except ValueError:
+                    return None
+    return None
+
+
+def stream_copy_gbs(dev):
+    """Measured device-to-device copy rate (bytes read + written per second) of a 1 GiB buffer."""
+    a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -220,13 +275,14 @@ def main():
         per_step = {k: v[0] / prof_steps for k, v in rep.items()}
         launches = {k: v[1] // prof_steps for k, v in rep.items()}
         dominant = max(per_step, key=per_step.get)
-        match_kernels = ("k_batch_setup", "k_grid_build", "k_proj_candidates", "k_proj_resolve")
-        bytes_key = "match" if dominant in match_kernels else dominant
-        alg_bytes_per_launch = STAGE_BYTES.get(bytes_key, 0) * n_frames / max(launches[dominant], 1)
+        bytes_key = STAGE_OF_KERNEL.get(dominant, dominant)
+        alg_bytes_per_launch = STAGE_BYTES[bytes_key] * n_frames / max(launches[dominant], 1)
         avg_ms = per_step[dominant] / max(launches[dominant], 1)
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dominant),
+                           "traffic_source": "profiles/r1_pmc_per_kernel.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                           "stream_copy_gbs": stream_copy_gbs(dev),
                            "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                            "path_bytes_per_frame": PATH_BYTES_PER_FRAME,
                            "path_achieved_gbs": PATH_BYTES_PER_FRAME * value / world / 1e9,
@@ -234,9 +290,11 @@ def main():
                            "kernel_ms_per_step": per_step}
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames[:min(n_frames, 257)].cpu().numpy()
-            fps, sample = cpu_baseline(host_frames, args.cpu_seconds)
-            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": 1, "kind": "port",
-                                   "sample": "%d consecutive frames of the same synthetic sequence, extract + match, one thread" % sample}
+            fps, sample, cores, single = cpu_baseline(host_frames, args.cpu_seconds)
+            out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+                                   "single_thread_value": single,
+                                   "sample": "%d frames of the same synthetic sequence in %d contiguous chunks (one halo frame each), "
+                                             "extract + match, one oracle thread per chunk" % (sample, cores)}
         print(json.dumps(out))
 
     if dist is not None:

@@ -1,0 +1,521 @@
+// ovs_shim.hpp -- header-only C++ layer with the class names and member signatures of
+// feature::orb_extractor (src/openvslam/feature/orb_extractor.h:18-78) and
+// match::{projection, robust, bow_tree, stereo} (src/openvslam/match/*.h) on top of the C ABI of
+// include/ovs.h.  The classes are templates over the caller's frame / keyframe / landmark /
+// matrix types and only use the member names the reference's own implementation uses
+// (landmarks_, undist_keypts_, descriptors_, stereo_x_right_, scale_factors_, camera_, ...), so in
+// the reference tree they are instantiated with data::frame, data::keyframe, data::landmark and
+// cv::Mat; this file itself includes neither OpenCV nor Eigen.
+//
+// What stays on the host, exactly where the reference has it: camera reprojection (double
+// precision), landmark getters (they take mutexes), the final pointer writes.  What moves to the
+// GPU: the window queries, every Hamming distance, best / second-best selection, the sequential
+// conflict resolution and the rotation histogram.
+//
+// Errors: the C ABI returns status codes; the shim throws std::runtime_error with
+// ovs_last_error(), which is what the reference's own failure modes (std::runtime_error from
+// orb_params, std::out_of_range from .at()) look like to a caller.
+#ifndef OVS_SHIM_HPP
+#define OVS_SHIM_HPP
+
+#include "ovs.h"
+
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace ovs_shim {
+
+inline void check(int rc) {
+    if (rc != OVS_OK) {
+        throw std::runtime_error(std::string("ovs: ") + ovs_last_error());
+    }
+}
+
+// Adapter between the caller's 8-bit matrix type and raw memory.  Specialise for cv::Mat in the
+// reference tree (INTEGRATION.md shows the ten lines); the primary template fits any type with
+// data / cols / rows / step members and create(rows, cols).
+template <class Mat>
+struct mat_traits {
+    static bool empty(const Mat& m) { return m.data == nullptr || m.cols == 0 || m.rows == 0; }
+    static const uint8_t* data(const Mat& m) { return m.data; }
+    static uint8_t* data(Mat& m) { return m.data; }
+    static int cols(const Mat& m) { return m.cols; }
+    static int rows(const Mat& m) { return m.rows; }
+    static size_t step(const Mat& m) { return static_cast<size_t>(m.step); }
+    static void create_u8(Mat& m, int rows, int cols) { m.create(rows, cols); }
+    static void release(Mat& m) { m.release(); }
+};
+
+inline ovs_grid make_grid(float min_x, float min_y, float max_x, float max_y, double inv_cell_width, double inv_cell_height,
+                          unsigned num_cols, unsigned num_rows) {
+    ovs_grid g;
+    g.min_x = min_x; g.min_y = min_y; g.max_x = max_x; g.max_y = max_y;
+    g.inv_cell_width = inv_cell_width; g.inv_cell_height = inv_cell_height;
+    g.num_cols = num_cols; g.num_rows = num_rows;
+    return g;
+}
+
+// camera::base keeps the grid geometry (camera/base.h:117-130)
+template <class Camera>
+ovs_grid grid_of(const Camera& cam) {
+    return make_grid(cam.img_bounds_.min_x_, cam.img_bounds_.min_y_, cam.img_bounds_.max_x_, cam.img_bounds_.max_y_,
+                     cam.inv_cell_width_, cam.inv_cell_height_, cam.num_grid_cols_, cam.num_grid_rows_);
+}
+
+// Flattened copy of what the matchers read from a frame / keyframe.  cv::KeyPoint has the layout
+// of ovs_keypoint (checked at compile time where it is used).
+struct frame_arrays {
+    std::vector<ovs_keypoint> undist_keypts;
+    std::vector<uint8_t> descriptors;
+    std::vector<float> stereo_x_right;
+    std::vector<float> scale_factors;
+    ovs_frame_view view;
+};
+
+template <class Frame>
+void flatten_frame(const Frame& frm, frame_arrays& out) {
+    typedef typename std::remove_reference<decltype(frm.undist_keypts_.at(0))>::type keypoint_t;
+    static_assert(sizeof(keypoint_t) == sizeof(ovs_keypoint), "cv::KeyPoint layout expected");
+    const size_t n = frm.undist_keypts_.size();
+    out.undist_keypts.resize(n);
+    if (n) {
+        std::memcpy(out.undist_keypts.data(), frm.undist_keypts_.data(), n * sizeof(ovs_keypoint));
+    }
+    typedef mat_traits<typename std::remove_cv<typename std::remove_reference<decltype(frm.descriptors_)>::type>::type> mt;
+    out.descriptors.resize(n * 32);
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(out.descriptors.data() + 32 * i, mt::data(frm.descriptors_) + mt::step(frm.descriptors_) * i, 32);
+    }
+    out.stereo_x_right.assign(frm.stereo_x_right_.begin(), frm.stereo_x_right_.end());
+    out.scale_factors.assign(frm.scale_factors_.begin(), frm.scale_factors_.end());
+    out.view.num_keypts = static_cast<int32_t>(n);
+    out.view.undist_keypts = out.undist_keypts.data();
+    out.view.descriptors = out.descriptors.data();
+    out.view.stereo_x_right = out.stereo_x_right.size() == n && n ? out.stereo_x_right.data() : nullptr;
+    out.view.scale_factors = out.scale_factors.data();
+    out.view.num_scale_levels = static_cast<int32_t>(out.scale_factors.size());
+    out.view.grid = grid_of(*frm.camera_);
+}
+
+struct query_arrays {
+    std::vector<float> reproj_xy, x_right, angle;
+    std::vector<int32_t> scale_level;
+    std::vector<uint8_t> desc, valid, has_observation;
+    ovs_proj_queries q;
+    void reserve(size_t n) {
+        reproj_xy.reserve(2 * n); x_right.reserve(n); angle.reserve(n); scale_level.reserve(n);
+        desc.reserve(32 * n); valid.reserve(n); has_observation.reserve(n);
+    }
+    template <class Mat>
+    void push(float x, float y, float xr, int level, float ang, const Mat& d, bool is_valid, bool has_obs) {
+        reproj_xy.push_back(x); reproj_xy.push_back(y); x_right.push_back(xr); scale_level.push_back(level); angle.push_back(ang);
+        const size_t o = desc.size();
+        desc.resize(o + 32, 0);
+        if (is_valid) {
+            std::memcpy(desc.data() + o, mat_traits<Mat>::data(d), 32);
+        }
+        valid.push_back(is_valid ? 1 : 0);
+        has_observation.push_back(has_obs ? 1 : 0);
+    }
+    const ovs_proj_queries* finish() {
+        q.n = static_cast<int32_t>(valid.size());
+        q.reproj_xy = reproj_xy.data(); q.x_right = x_right.data(); q.scale_level = scale_level.data(); q.angle = angle.data();
+        q.desc = desc.data(); q.valid = valid.data(); q.has_observation = has_observation.data();
+        return &q;
+    }
+};
+
+template <class LandmarkPtrVec>
+std::vector<uint8_t> occupied_flags(const LandmarkPtrVec& lms) {
+    // `landmarks_.at(idx) && landmarks_.at(idx)->has_observation()`, projection.cc:41,164
+    std::vector<uint8_t> occ(lms.size(), 0);
+    for (size_t i = 0; i < lms.size(); ++i) {
+        occ[i] = (lms[i] && lms[i]->has_observation()) ? 1 : 0;
+    }
+    return occ;
+}
+
+namespace feature {
+
+struct orb_params {
+    unsigned int max_num_keypts_ = 2000;
+    float scale_factor_ = 1.2f;
+    unsigned int num_levels_ = 8;
+    unsigned int ini_fast_thr_ = 20;
+    unsigned int min_fast_thr = 7;
+    std::vector<std::vector<float>> mask_rects_;
+};
+
+// orb_extractor.h:18-78.  One instance per camera stream and thread, as in the reference.
+class orb_extractor {
+public:
+    orb_extractor() = delete;
+    explicit orb_extractor(const orb_params& params, int device = 0) {
+        std::vector<float> rects;
+        for (const auto& r : params.mask_rects_) {
+            if (r.size() != 4) {
+                throw std::runtime_error("mask rectangle must contain four parameters");
+            }
+            rects.insert(rects.end(), r.begin(), r.end());
+        }
+        ovs_orb_params p;
+        p.max_num_keypts = params.max_num_keypts_;
+        p.scale_factor = params.scale_factor_;
+        p.num_levels = params.num_levels_;
+        p.ini_fast_thr = params.ini_fast_thr_;
+        p.min_fast_thr = params.min_fast_thr;
+        p.num_mask_rects = static_cast<uint32_t>(params.mask_rects_.size());
+        p.mask_rects = rects.empty() ? nullptr : rects.data();
+        check(ovs_orb_create(&p, device, &h_));
+    }
+    orb_extractor(unsigned int max_num_keypts, float scale_factor, unsigned int num_levels, unsigned int ini_fast_thr,
+                  unsigned int min_fast_thr, const std::vector<std::vector<float>>& mask_rects = {}, int device = 0)
+        : orb_extractor(make_params(max_num_keypts, scale_factor, num_levels, ini_fast_thr, min_fast_thr, mask_rects), device) {}
+    orb_extractor(const orb_extractor&) = delete;
+    orb_extractor& operator=(const orb_extractor&) = delete;
+    virtual ~orb_extractor() { ovs_orb_destroy(h_); }
+
+    // extract(in_image, in_image_mask, keypts, out_descriptors), orb_extractor.cc:68-144
+    template <class Mat, class KeyPoint>
+    void extract(const Mat& in_image, const Mat& in_image_mask, std::vector<KeyPoint>& keypts, Mat& out_descriptors) {
+        static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout expected");
+        typedef mat_traits<Mat> mt;
+        if (mt::empty(in_image)) {
+            return;
+        }
+        const int w = mt::cols(in_image), h = mt::rows(in_image);
+        const int cap = ovs_orb_keypoint_capacity(h_, w, h);
+        if (cap < 0) {
+            check(cap);
+        }
+        kps_.resize(static_cast<size_t>(cap));
+        desc_.resize(static_cast<size_t>(cap) * 32);
+        int n = 0;
+        const bool has_mask = !mt::empty(in_image_mask);
+        check(ovs_orb_extract(h_, mt::data(in_image), w, h, mt::step(in_image), has_mask ? mt::data(in_image_mask) : nullptr,
+                              has_mask ? mt::step(in_image_mask) : 0, kps_.data(), desc_.data(), cap, &n));
+        // image_pyramid_ is public in the reference and read by match::stereo after extract()
+        image_pyramid_.resize(get_num_scale_levels());
+        keypts.resize(static_cast<size_t>(n));
+        if (n == 0) {
+            mt::release(out_descriptors);
+            return;
+        }
+        std::memcpy(static_cast<void*>(keypts.data()), kps_.data(), static_cast<size_t>(n) * sizeof(ovs_keypoint));
+        mt::create_u8(out_descriptors, n, 32);
+        for (int i = 0; i < n; ++i) {
+            std::memcpy(mt::data(out_descriptors) + mt::step(out_descriptors) * i, desc_.data() + 32 * static_cast<size_t>(i), 32);
+        }
+        last_w_ = w;
+        last_h_ = h;
+        last_level0_ = mt::data(in_image);
+        last_level0_step_ = mt::step(in_image);
+    }
+
+    unsigned int get_max_num_keypoints() const { return ovs_orb_get_max_num_keypoints(h_); }
+    void set_max_num_keypoints(unsigned int v) { check(ovs_orb_set_max_num_keypoints(h_, v)); }
+    float get_scale_factor() const { return ovs_orb_get_scale_factor(h_); }
+    void set_scale_factor(float v) { check(ovs_orb_set_scale_factor(h_, v)); }
+    unsigned int get_num_scale_levels() const { return ovs_orb_get_num_scale_levels(h_); }
+    void set_num_scale_levels(unsigned int v) { check(ovs_orb_set_num_scale_levels(h_, v)); }
+    unsigned int get_initial_fast_threshold() const { return ovs_orb_get_initial_fast_threshold(h_); }
+    void set_initial_fast_threshold(unsigned int v) { check(ovs_orb_set_initial_fast_threshold(h_, v)); }
+    unsigned int get_minimum_fast_threshold() const { return ovs_orb_get_minimum_fast_threshold(h_); }
+    void set_minimum_fast_threshold(unsigned int v) { check(ovs_orb_set_minimum_fast_threshold(h_, v)); }
+    std::vector<float> get_scale_factors() const { return table(ovs_orb_get_scale_factors); }
+    std::vector<float> get_inv_scale_factors() const { return table(ovs_orb_get_inv_scale_factors); }
+    std::vector<float> get_level_sigma_sq() const { return table(ovs_orb_get_level_sigma_sq); }
+    std::vector<float> get_inv_level_sigma_sq() const { return table(ovs_orb_get_inv_level_sigma_sq); }
+
+    // Host copy of one level of image_pyramid_ of the last extract() (level 0 is the caller's image).
+    struct plane {
+        std::vector<uint8_t> pixels;
+        int width = 0, height = 0;
+    };
+    plane image_pyramid_level(unsigned int level) {
+        plane pl;
+        check(ovs_orb_level_size(h_, last_w_, last_h_, static_cast<int>(level), &pl.width, &pl.height));
+        pl.pixels.resize(static_cast<size_t>(pl.width) * pl.height);
+        if (level == 0) {
+            for (int y = 0; y < pl.height; ++y) {
+                std::memcpy(pl.pixels.data() + static_cast<size_t>(y) * pl.width, last_level0_ + last_level0_step_ * y, pl.width);
+            }
+        }
+        else {
+            check(ovs_orb_download_pyramid_level(h_, 0, static_cast<int>(level), pl.pixels.data(), pl.width));
+        }
+        return pl;
+    }
+    std::vector<plane> image_pyramid_; // filled lazily by match::stereo through image_pyramid_level()
+
+    ovs_orb* handle() { return h_; }
+
+private:
+    static orb_params make_params(unsigned int n, float s, unsigned int l, unsigned int ini, unsigned int mn,
+                                  const std::vector<std::vector<float>>& rects) {
+        orb_params p;
+        p.max_num_keypts_ = n; p.scale_factor_ = s; p.num_levels_ = l; p.ini_fast_thr_ = ini; p.min_fast_thr = mn; p.mask_rects_ = rects;
+        return p;
+    }
+    std::vector<float> table(int (*fn)(const ovs_orb*, float*)) const {
+        std::vector<float> t(get_num_scale_levels());
+        check(fn(h_, t.data()));
+        return t;
+    }
+    ovs_orb* h_ = nullptr;
+    std::vector<ovs_keypoint> kps_;
+    std::vector<uint8_t> desc_;
+    int last_w_ = 0, last_h_ = 0;
+    const uint8_t* last_level0_ = nullptr;
+    size_t last_level0_step_ = 0;
+};
+
+} // namespace feature
+
+namespace match {
+
+// match/base.h:65-75
+class base {
+public:
+    base(const float lowe_ratio, const bool check_orientation, int device = 0)
+        : lowe_ratio_(lowe_ratio), check_orientation_(check_orientation), device_(device) {}
+    virtual ~base() = default;
+
+protected:
+    const float lowe_ratio_;
+    const bool check_orientation_;
+    const int device_;
+};
+
+class projection final : public base {
+public:
+    explicit projection(const float lowe_ratio = 0.6, const bool check_orientation = true, int device = 0)
+        : base(lowe_ratio, check_orientation, device) {}
+
+    // projection.cc:11-82
+    template <class Frame, class Landmark>
+    unsigned int match_frame_and_landmarks(Frame& frm, const std::vector<Landmark*>& local_landmarks, const float margin = 5.0) const {
+        frame_arrays fa;
+        flatten_frame(frm, fa);
+        query_arrays qa;
+        qa.reserve(local_landmarks.size());
+        for (auto* lm : local_landmarks) {
+            const bool valid = lm->is_observable_in_tracking_ && !lm->will_be_erased();
+            const auto desc = lm->get_descriptor();
+            qa.push(lm->reproj_in_tracking_(0), lm->reproj_in_tracking_(1), lm->x_right_in_tracking_,
+                    static_cast<int>(lm->scale_level_in_tracking_), 0.0f, desc, valid, lm->has_observation());
+        }
+        const std::vector<uint8_t> occ = occupied_flags(frm.landmarks_);
+        std::vector<int32_t> matched(frm.landmarks_.size(), -1);
+        uint32_t num = 0;
+        check(ovs_match_frame_and_landmarks(&fa.view, qa.finish(), occ.data(), margin, lowe_ratio_, matched.data(), &num, device_));
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                frm.landmarks_.at(i) = local_landmarks.at(matched[i]);
+            }
+        }
+        return num;
+    }
+
+    // projection.cc:84-209
+    template <class Frame>
+    unsigned int match_current_and_last_frames(Frame& curr_frm, const Frame& last_frm, const float margin) const {
+        const auto rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0).eval();
+        const auto trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3).eval();
+        const auto trans_wc = (-rot_cw.transpose() * trans_cw).eval();
+        const auto rot_lw = last_frm.cam_pose_cw_.template block<3, 3>(0, 0).eval();
+        const auto trans_lw = last_frm.cam_pose_cw_.template block<3, 1>(0, 3).eval();
+        const auto trans_lc = (rot_lw * trans_wc + trans_lw).eval();
+        // camera::setup_type_t::Monocular == 0 (camera/base.h:16-17)
+        const bool mono = static_cast<int>(curr_frm.camera_->setup_type_) == 0;
+        const bool assume_forward = mono ? false : trans_lc(2) > curr_frm.camera_->true_baseline_;
+        const bool assume_backward = mono ? false : -trans_lc(2) > curr_frm.camera_->true_baseline_;
+        const int direction = assume_forward ? OVS_DIR_FORWARD : (assume_backward ? OVS_DIR_BACKWARD : OVS_DIR_NONE);
+
+        frame_arrays fa;
+        flatten_frame(curr_frm, fa);
+        query_arrays qa;
+        qa.reserve(last_frm.num_keypts_);
+        typedef typename std::remove_reference<decltype(*last_frm.landmarks_.at(0))>::type landmark_t;
+        std::vector<landmark_t*> query_lms;
+        query_lms.reserve(last_frm.num_keypts_);
+        for (unsigned int idx_last = 0; idx_last < last_frm.num_keypts_; ++idx_last) {
+            auto* lm = last_frm.landmarks_.at(idx_last);
+            if (!lm || last_frm.outlier_flags_.at(idx_last)) {
+                continue;
+            }
+            const auto pos_w = lm->get_pos_in_world();
+            typename std::remove_cv<typename std::remove_reference<decltype(lm->reproj_in_tracking_)>::type>::type reproj; // Vec2_t
+            float x_right;
+            if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) {
+                continue;
+            }
+            const auto desc = lm->get_descriptor();
+            qa.push(reproj(0), reproj(1), x_right, last_frm.keypts_.at(idx_last).octave, last_frm.undist_keypts_.at(idx_last).angle,
+                    desc, true, lm->has_observation());
+            query_lms.push_back(lm);
+        }
+        const std::vector<uint8_t> occ = occupied_flags(curr_frm.landmarks_);
+        std::vector<int32_t> matched(curr_frm.landmarks_.size(), -1);
+        uint32_t num = 0;
+        check(ovs_match_current_and_last_frames(&fa.view, qa.finish(), occ.data(), margin, direction,
+                                                static_cast<int>(last_frm.num_scale_levels_), lowe_ratio_, check_orientation_ ? 1 : 0,
+                                                matched.data(), &num, device_));
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                curr_frm.landmarks_.at(i) = query_lms.at(matched[i]);
+            }
+            else if (matched[i] == -2) {
+                curr_frm.landmarks_.at(i) = nullptr; // written, then cleared by the rotation check (projection.cc:203)
+            }
+        }
+        return num;
+    }
+};
+
+class robust final : public base {
+public:
+    explicit robust(const float lowe_ratio = 0.75, const bool check_orientation = true, int device = 0)
+        : base(lowe_ratio, check_orientation, device) {}
+
+    // robust.cc:209-315
+    template <class Frame, class Keyframe>
+    unsigned int brute_force_match(Frame& frm, Keyframe* keyfrm, std::vector<std::pair<int, int>>& matches) const {
+        frame_arrays f1, f2;
+        flatten_frame(frm, f1);
+        flatten_frame(*keyfrm, f2);
+        // the rotation check of this matcher uses keypts_, not undist_keypts_ (robust.cc:289)
+        std::vector<float> a1(frm.keypts_.size()), a2(keyfrm->keypts_.size());
+        for (size_t i = 0; i < a1.size(); ++i) a1[i] = frm.keypts_[i].angle;
+        for (size_t i = 0; i < a2.size(); ++i) a2[i] = keyfrm->keypts_[i].angle;
+        const auto lms_2 = keyfrm->get_landmarks();
+        std::vector<uint8_t> valid_2(lms_2.size(), 0);
+        for (size_t i = 0; i < lms_2.size(); ++i) {
+            valid_2[i] = (lms_2[i] && !lms_2[i]->will_be_erased()) ? 1 : 0;
+        }
+        std::vector<int32_t> pairs(2 * a1.size() + 2);
+        uint32_t num = 0;
+        check(ovs_brute_force_match(f1.descriptors.data(), a1.data(), static_cast<int>(a1.size()), f2.descriptors.data(), a2.data(),
+                                    valid_2.data(), static_cast<int>(a2.size()), lowe_ratio_, check_orientation_ ? 1 : 0,
+                                    pairs.data(), &num, device_));
+        matches.clear();
+        matches.reserve(num);
+        for (uint32_t i = 0; i < num; ++i) {
+            matches.emplace_back(pairs[2 * i], pairs[2 * i + 1]);
+        }
+        return num;
+    }
+};
+
+// DBoW2::FeatureVector is a std::map<unsigned, std::vector<unsigned>>: flattened in key order
+struct bow_arrays {
+    std::vector<uint32_t> node_ids, offsets, indices;
+    ovs_bow_feat_vec v;
+    template <class FeatureVector>
+    explicit bow_arrays(const FeatureVector& fv) {
+        offsets.push_back(0);
+        for (const auto& kv : fv) {
+            node_ids.push_back(static_cast<uint32_t>(kv.first));
+            indices.insert(indices.end(), kv.second.begin(), kv.second.end());
+            offsets.push_back(static_cast<uint32_t>(indices.size()));
+        }
+        v.num_nodes = static_cast<int32_t>(node_ids.size());
+        v.node_ids = node_ids.data(); v.offsets = offsets.data(); v.indices = indices.data();
+    }
+};
+
+class bow_tree final : public base {
+public:
+    explicit bow_tree(const float lowe_ratio = 0.6, const bool check_orientation = true, int device = 0)
+        : base(lowe_ratio, check_orientation, device) {}
+
+    // bow_tree.cc:16-122
+    template <class Keyframe, class Frame, class Landmark>
+    unsigned int match_frame_and_keyframe(Keyframe* keyfrm, Frame& frm, std::vector<Landmark*>& matched_lms_in_frm) const {
+        frame_arrays fk, ff;
+        flatten_frame(*keyfrm, fk);
+        flatten_frame(frm, ff);
+        std::vector<float> ak(fk.undist_keypts.size()), af(ff.undist_keypts.size());
+        for (size_t i = 0; i < ak.size(); ++i) ak[i] = fk.undist_keypts[i].angle;
+        for (size_t i = 0; i < af.size(); ++i) af[i] = ff.undist_keypts[i].angle;
+        const auto keyfrm_lms = keyfrm->get_landmarks();
+        std::vector<uint8_t> valid(keyfrm_lms.size(), 0);
+        for (size_t i = 0; i < keyfrm_lms.size(); ++i) {
+            valid[i] = (keyfrm_lms[i] && !keyfrm_lms[i]->will_be_erased()) ? 1 : 0;
+        }
+        const bow_arrays bk(keyfrm->bow_feat_vec_), bf(frm.bow_feat_vec_);
+        std::vector<int32_t> matched(af.size(), -1);
+        uint32_t num = 0;
+        check(ovs_bow_match_frame_and_keyframe(&bk.v, fk.descriptors.data(), ak.data(), valid.data(), static_cast<int>(ak.size()),
+                                               &bf.v, ff.descriptors.data(), af.data(), static_cast<int>(af.size()),
+                                               lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num, device_));
+        matched_lms_in_frm = std::vector<Landmark*>(af.size(), nullptr);
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                matched_lms_in_frm[i] = keyfrm_lms.at(matched[i]);
+            }
+        }
+        return num;
+    }
+};
+
+// match/stereo.h: constructed from the two extractors' pyramids, keypoints and descriptors
+class stereo {
+public:
+    template <class KeyPoint, class Mat>
+    stereo(feature::orb_extractor& left, feature::orb_extractor& right, const std::vector<KeyPoint>& keypts_left,
+           const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right,
+           const std::vector<float>& scale_factors, const std::vector<float>& inv_scale_factors,
+           const float focal_x_baseline, const float true_baseline, int device = 0)
+        : scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors), focal_x_baseline_(focal_x_baseline),
+          true_baseline_(true_baseline), device_(device) {
+        static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout expected");
+        const unsigned levels = left.get_num_scale_levels();
+        for (unsigned l = 0; l < levels; ++l) {
+            left_.push_back(left.image_pyramid_level(l));
+            right_.push_back(right.image_pyramid_level(l));
+        }
+        kl_.resize(keypts_left.size());
+        kr_.resize(keypts_right.size());
+        if (!kl_.empty()) std::memcpy(kl_.data(), keypts_left.data(), kl_.size() * sizeof(ovs_keypoint));
+        if (!kr_.empty()) std::memcpy(kr_.data(), keypts_right.data(), kr_.size() * sizeof(ovs_keypoint));
+        typedef mat_traits<Mat> mt;
+        dl_.resize(kl_.size() * 32);
+        dr_.resize(kr_.size() * 32);
+        for (size_t i = 0; i < kl_.size(); ++i) std::memcpy(dl_.data() + 32 * i, mt::data(descs_left) + mt::step(descs_left) * i, 32);
+        for (size_t i = 0; i < kr_.size(); ++i) std::memcpy(dr_.data() + 32 * i, mt::data(descs_right) + mt::step(descs_right) * i, 32);
+    }
+
+    // stereo.cc:18-113
+    void compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
+        std::vector<ovs_image_view> lv(left_.size()), rv(right_.size());
+        for (size_t l = 0; l < left_.size(); ++l) {
+            lv[l].data = left_[l].pixels.data(); lv[l].width = left_[l].width; lv[l].height = left_[l].height; lv[l].stride = left_[l].width;
+            rv[l].data = right_[l].pixels.data(); rv[l].width = right_[l].width; rv[l].height = right_[l].height; rv[l].stride = right_[l].width;
+        }
+        stereo_x_right.assign(kl_.size(), -1.0f);
+        depths.assign(kl_.size(), -1.0f);
+        check(ovs_stereo_compute(lv.data(), rv.data(), static_cast<int>(lv.size()), kl_.data(), static_cast<int>(kl_.size()),
+                                 kr_.data(), static_cast<int>(kr_.size()), dl_.data(), dr_.data(), scale_factors_.data(),
+                                 inv_scale_factors_.data(), focal_x_baseline_, true_baseline_, stereo_x_right.data(), depths.data(), device_));
+    }
+
+private:
+    std::vector<feature::orb_extractor::plane> left_, right_;
+    std::vector<ovs_keypoint> kl_, kr_;
+    std::vector<uint8_t> dl_, dr_;
+    const std::vector<float> scale_factors_, inv_scale_factors_;
+    const float focal_x_baseline_, true_baseline_;
+    const int device_;
+};
+
+} // namespace match
+} // namespace ovs_shim
+
+#endif

@@ -1,0 +1,178 @@
+// Compiles the header-only C++ shim against small stand-ins for the CALLER's types (a frame with
+// the member names of data::frame, a landmark, a 4x4 pose with block<>(), an 8-bit matrix) and
+// links it with libovs_hip.so.  Without a GPU the program only checks that construction fails
+// with the library's "no HIP device" error; with a GPU (argv[1] == "run") it extracts two frames
+// and runs the matchers, printing counts for the Python side to compare.
+#include "ovs_shim.hpp"
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+
+namespace mock {
+
+struct vec2 {
+    double v[2] = {0, 0};
+    double operator()(int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+};
+struct vec3 {
+    double v[3] = {0, 0, 0};
+    double operator()(int i) const { return v[i]; }
+    double& operator()(int i) { return v[i]; }
+    vec3 eval() const { return *this; }
+    vec3 operator-() const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = -v[i]; return r; }
+    vec3 operator+(const vec3& o) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+};
+struct mat33 {
+    double m[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    mat33 eval() const { return *this; }
+    mat33 transpose() const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
+    mat33 operator-() const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = -m[i][j]; return r; }
+    vec3 operator*(const vec3& x) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2]; return r; }
+};
+template <int R, int C> struct block_type;
+template <> struct block_type<3, 3> { typedef mat33 type; };
+template <> struct block_type<3, 1> { typedef vec3 type; };
+struct mat44 {
+    double m[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    template <int R, int C>
+    typename block_type<R, C>::type block(int r0, int c0) const;
+};
+template <> mat33 mat44::block<3, 3>(int r0, int c0) const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[r0 + i][c0 + j]; return r; }
+template <> vec3 mat44::block<3, 1>(int r0, int c0) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = m[r0 + i][c0]; return r; }
+
+struct mat_u8 {
+    uint8_t* data = nullptr;
+    int cols = 0, rows = 0;
+    size_t step = 0;
+    std::shared_ptr<std::vector<uint8_t>> store;
+    void create(int r, int c) {
+        store = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(r) * c);
+        data = store->data(); rows = r; cols = c; step = c;
+    }
+    void release() { store.reset(); data = nullptr; rows = cols = 0; step = 0; }
+};
+
+struct keypoint { float x, y, size, angle, response; int octave, class_id; };
+
+struct bounds { float min_x_, min_y_, max_x_, max_y_; };
+struct camera {
+    int setup_type_ = 0; // Monocular
+    float true_baseline_ = 0.0f;
+    bounds img_bounds_;
+    double inv_cell_width_, inv_cell_height_;
+    unsigned num_grid_cols_ = 64, num_grid_rows_ = 48;
+    double fx = 500, fy = 500, cx = 320, cy = 240;
+    bool reproject_to_image(const mat33& rot_cw, const vec3& trans_cw, const vec3& pos_w, vec2& reproj, float& x_right) const {
+        const vec3 pc = rot_cw * pos_w + trans_cw;
+        if (pc(2) <= 0) return false;
+        reproj(0) = fx * pc(0) / pc(2) + cx;
+        reproj(1) = fy * pc(1) / pc(2) + cy;
+        x_right = -1.0f;
+        return img_bounds_.min_x_ <= reproj(0) && reproj(0) <= img_bounds_.max_x_ && img_bounds_.min_y_ <= reproj(1) && reproj(1) <= img_bounds_.max_y_;
+    }
+};
+
+struct landmark {
+    vec3 pos;
+    mat_u8 desc;
+    vec2 reproj_in_tracking_;
+    float x_right_in_tracking_ = -1.0f;
+    bool is_observable_in_tracking_ = true;
+    int scale_level_in_tracking_ = 0;
+    bool observed = true;
+    vec3 get_pos_in_world() const { return pos; }
+    mat_u8 get_descriptor() const { return desc; }
+    bool has_observation() const { return observed; }
+    bool will_be_erased() const { return false; }
+};
+
+struct frame {
+    unsigned int num_keypts_ = 0;
+    std::vector<keypoint> keypts_, undist_keypts_;
+    mat_u8 descriptors_;
+    std::vector<float> stereo_x_right_;
+    std::vector<float> scale_factors_;
+    unsigned int num_scale_levels_ = 8;
+    std::vector<landmark*> landmarks_;
+    std::vector<bool> outlier_flags_;
+    mat44 cam_pose_cw_;
+    camera* camera_ = nullptr;
+    std::map<unsigned, std::vector<unsigned>> bow_feat_vec_;
+    std::vector<landmark*> get_landmarks() const { return landmarks_; }
+};
+
+} // namespace mock
+
+static void make_image(mock::mat_u8& img, int w, int h, int shift) {
+    img.create(h, w);
+    unsigned s = 12345;
+    std::vector<uint8_t> canvas(static_cast<size_t>(w + 64) * h);
+    for (auto& v : canvas) { s = s * 1664525u + 1013904223u; v = static_cast<uint8_t>(128 + ((s >> 24) & 31)); }
+    for (int k = 0; k < 400; ++k) {
+        s = s * 1664525u + 1013904223u; const int x0 = (s >> 8) % (w + 30);
+        s = s * 1664525u + 1013904223u; const int y0 = (s >> 8) % (h - 20);
+        s = s * 1664525u + 1013904223u; const uint8_t g = static_cast<uint8_t>(s >> 24);
+        for (int y = y0; y < y0 + 14; ++y) for (int x = x0; x < x0 + 18; ++x) canvas[static_cast<size_t>(y) * (w + 64) + x] = g;
+    }
+    for (int y = 0; y < h; ++y) std::memcpy(img.data + static_cast<size_t>(y) * w, canvas.data() + static_cast<size_t>(y) * (w + 64) + shift, w);
+}
+
+int main(int argc, char** argv) {
+    using namespace ovs_shim;
+    const bool run = argc > 1 && std::string(argv[1]) == "run";
+    if (!run) {
+        try {
+            feature::orb_extractor ext(feature::orb_params{});
+            if (ovs_device_count() <= 0) { std::puts("FAIL: constructed without a GPU"); return 1; }
+            std::puts("OK gpu-present");
+        }
+        catch (const std::runtime_error& e) {
+            std::printf("OK no-gpu: %s\n", e.what());
+        }
+        return 0;
+    }
+    const int w = 640, h = 480, dx = 4;
+    feature::orb_params prm;
+    prm.max_num_keypts_ = 1000;
+    feature::orb_extractor ext(prm);
+    mock::camera cam;
+    cam.img_bounds_ = {0.0f, 0.0f, static_cast<float>(w), static_cast<float>(h)};
+    cam.inv_cell_width_ = 64.0 / w; cam.inv_cell_height_ = 48.0 / h;
+    cam.cx = 0; cam.cy = 0; cam.fx = 1; cam.fy = 1;
+    mock::frame frm[2];
+    mock::mat_u8 img[2], no_mask;
+    for (int f = 0; f < 2; ++f) {
+        make_image(img[f], w, h, f * dx);
+        ext.extract(img[f], no_mask, frm[f].keypts_, frm[f].descriptors_);
+        frm[f].undist_keypts_ = frm[f].keypts_;
+        frm[f].num_keypts_ = static_cast<unsigned>(frm[f].keypts_.size());
+        frm[f].stereo_x_right_.assign(frm[f].num_keypts_, -1.0f);
+        frm[f].scale_factors_ = ext.get_scale_factors();
+        frm[f].landmarks_.assign(frm[f].num_keypts_, nullptr);
+        frm[f].outlier_flags_.assign(frm[f].num_keypts_, false);
+        frm[f].camera_ = &cam;
+    }
+    // every keypoint of frame 0 carries a landmark at depth 1 whose projection (fx = fy = 1, pose
+    // = identity) into frame 1 is its pixel position shifted by -dx
+    std::vector<std::unique_ptr<mock::landmark>> lms;
+    for (unsigned i = 0; i < frm[0].num_keypts_; ++i) {
+        lms.emplace_back(new mock::landmark);
+        lms.back()->pos.v[0] = frm[0].keypts_[i].x - dx; lms.back()->pos.v[1] = frm[0].keypts_[i].y; lms.back()->pos.v[2] = 1.0;
+        lms.back()->desc.create(1, 32);
+        std::memcpy(lms.back()->desc.data, frm[0].descriptors_.data + 32 * static_cast<size_t>(i), 32);
+        frm[0].landmarks_[i] = lms.back().get();
+    }
+    const unsigned n_proj = match::projection(0.9f, true).match_current_and_last_frames(frm[1], frm[0], 15.0f);
+    unsigned written = 0;
+    for (auto* lm : frm[1].landmarks_) written += lm != nullptr;
+    std::vector<std::pair<int, int>> pairs;
+    const unsigned n_bf = match::robust(0.75f, true).brute_force_match(frm[1], &frm[0], pairs);
+    std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu\n", frm[0].num_keypts_, frm[1].num_keypts_, n_proj,
+                written, n_bf, pairs.size());
+    return (n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100) ? 0 : 2;
+}
