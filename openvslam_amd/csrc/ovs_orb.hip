@@ -1450,102 +1450,167 @@ __device__ __forceinline__ int group_sum_i32(int v) {
     return v;
 }
 
-// 16 lanes per keypoint, 16 keypoints per workgroup.  Lane g of a group owns rows g - 15 and
-// g + 1 of the radius-15 disc (integer moments, reduced across the group: exact in any order) and
-// pairs 16g .. 16g+15 of the pattern, i.e. bytes 2g and 2g+1 of the descriptor.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 16 lanes per keypoint, 16 keypoints per workgroup.  Scattered byte reads from global memory cost
+// one cache-line lookup per lane, so both patches are fetched with row-contiguous dword loads:
+//   * moments: lane (h, q) = (g >> 3, g & 7) reads dword q of disc rows v = -15 + 2i + h; a
+//     per-row byte mask (LDS table indexed by |v|) cuts the dword to |u| <= u_max[|v|], then
+//     sum I and sum (u + 16) I are two v_dot4_u32_u8; integer sums, reduced across the group;
+//   * descriptor: the 37 x 37 neighbourhood of the blurred level (pattern radius 13 rotated:
+//     <= 18.4) goes to LDS as 37 rows of 11 aligned dwords; the 512 rotated sample reads are LDS
+//     byte reads.  Lane g owns pairs 16g .. 16g+15, i.e. bytes 2g and 2g+1 of the descriptor;
+//   * pattern: converted once per workgroup to fp32 in LDS (padded so a group's 16 lanes hit
+//     distinct banks); the rotation runs on packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are plain
+//     IEEE multiplies and adds, so the reference's mul, mul, add order and rounding are kept),
+//     cvRound = v_cvt_i32_f32 (nearest even);
+//   * descriptor bits are collected with sub + v_alignbit (sign bit shifted in), reversed once.
+constexpr int kPatchR = 18;                 // rows / columns -18 .. 18
+constexpr int kPatchRows = 2 * kPatchR + 1; // 37
+constexpr int kPatchDwords = 11;            // 44 bytes per row: 37 + up to 3 bytes of alignment
+constexpr int kPatchBytes = kPatchRows * kPatchDwords * 4;
+
 __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, const uint8_t* __restrict__ blur,
                                                      const u32* __restrict__ lvl_xy, const uint8_t* __restrict__ lvl_resp,
                                                      const int* __restrict__ lvl_count,
                                                      ovs_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                      int* __restrict__ out_counts, int cap) {
+    __shared__ float4 pat[16 * 17];   // (x0, y0, x1, y1) of pair 16 g + k at [17 g + k]
+    __shared__ u32 disc_mask[17][8];  // byte masks of a disc row by |v|; row 16 = empty
+    __shared__ __attribute__((aligned(16))) uint8_t patch[16][kPatchBytes];
+
     const int frame = blockIdx.y;
     const int gl = threadIdx.x & (kKpGroup - 1);
-    const int j = blockIdx.x * (256 / kKpGroup) + (threadIdx.x / kKpGroup); // slot in the per-frame level-keypoint arrays
-    if (j >= p.kp_total_cap) {
-        return;
-    }
-    int level = 0;
-#pragma unroll 1
-    for (int l = 1; l < p.num_levels; ++l) {
-        if (j >= p.lv[l].kp_base) {
-            level = l;
-        }
-    }
-    const level_geom& g = p.lv[level];
-    const int slot = j - g.kp_base;
-    // per-level counts of the frame: one lane per level (num_levels <= 16 = group width)
+    const int grp = threadIdx.x / kKpGroup;
+    // Output slot oi of the frame (level-major concatenation, orb_extractor.cc:120-143) is keypoint
+    // oi - before(level) of the level whose running count first exceeds oi.  Per-level counts:
+    // one lane per level (num_levels <= 16 = group width), inclusive scan over the group.
     const int myc = gl < p.num_levels ? lvl_count[frame * p.num_levels + gl] : 0;
     const int bad = group_sum_i32<kKpGroup>(myc < 0 ? 1 : 0);
-    const int total = group_sum_i32<kKpGroup>(max(myc, 0));
-    const int before = group_sum_i32<kKpGroup>(gl < level ? max(myc, 0) : 0);
-    const int mycount = __shfl(myc, level, kKpGroup);
-    if (j == 0 && gl == 0) {
+    int incl = max(myc, 0);
+#pragma unroll
+    for (int d = 1; d < kKpGroup; d <<= 1) {
+        const int t = __shfl_up(incl, d, kKpGroup);
+        if (gl >= d) {
+            incl += t;
+        }
+    }
+    const int total = __shfl(incl, kKpGroup - 1, kKpGroup);
+    const int oi = blockIdx.x * (256 / kKpGroup) + grp;
+    if (oi == 0 && gl == 0) {
         // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
         out_counts[frame] = bad ? (int)0x80000000 : (total > cap ? -total : total);
     }
-    if (bad || slot >= mycount) {
+    const int n_out = bad ? 0 : min(total, cap);
+    if ((int)blockIdx.x * (256 / kKpGroup) >= n_out) {
+        return; // the whole workgroup is past the last keypoint (same decision in every thread)
+    }
+    {
+        const int t = threadIdx.x;
+        const int8_t* pp = &c_pattern[t * 4];
+        pat[(t >> 4) * 17 + (t & 15)] = make_float4((float)pp[0], (float)pp[1], (float)pp[2], (float)pp[3]);
+        if (t < 17 * 8) {
+            const int av = t >> 3, q = t & 7;
+            u32 m = 0;
+            if (av <= kHalfPatch) {
+                const int d = c_umax[av];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int u = 4 * q + b - 16;
+                    m |= ((u < 0 ? -u : u) <= d) ? (0xFFu << (8 * b)) : 0u;
+                }
+            }
+            disc_mask[av][q] = m;
+        }
+    }
+    __syncthreads();
+    if (oi >= n_out) {
         return;
     }
-    const int oi = before + slot;
-    if (oi >= cap) {
-        return;
-    }
+    // level = number of levels whose inclusive count is <= oi
+    const u64 le = __ballot(gl < p.num_levels && incl <= oi);
+    const int level = __popc((u32)(le >> (16 * (threadIdx.x >> 4 & 3))) & 0xFFFFu);
+    const int before = level == 0 ? 0 : __shfl(incl, level - 1, kKpGroup);
+    const level_geom& g = p.lv[level];
+    const int j = g.kp_base + (oi - before); // slot in the per-frame level-keypoint arrays
 
     const long long li = (long long)frame * p.kp_total_cap + j;
     const u32 xy = lvl_xy[li];
     const int px = (int)(xy & 0xFFFF) + kBorder, py = (int)(xy >> 16) + kBorder; // pt += min_border, orb_extractor.cc:384-385
     const int resp = lvl_resp[li];
 
-    long long pitch;
-    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
+    // ---- blurred neighbourhood -> LDS (issued first: the moments below hide its latency) ----
+    // blurred planes of the frame as one buffer; rows of a plane share their alignment (pitch is a
+    // multiple of 64), so the patch is 37 rows of 11 dwords starting at the aligned address at or
+    // below its first byte
+    const __amdgpu_buffer_rsrc_t bplane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(blur) + frame * p.frame_blur_bytes, 0,
+                                                                            (int)p.frame_blur_bytes, 0x00020000);
+    const int step = g.pitch;
+    const int first = (int)g.blur_off + (py - kPatchR) * step + px - kPatchR; // byte (-18, -18)
+    const int first_al = first & ~3, sh = first & 3;
+    u32* my_patch = reinterpret_cast<u32*>(&patch[grp][0]);
+    constexpr int kPatchLoads = (kPatchRows * kPatchDwords + kKpGroup - 1) / kKpGroup; // 26
+    u32 staged[kPatchLoads];
+#pragma unroll
+    for (int t = 0; t < kPatchLoads; ++t) {
+        const int i = t * kKpGroup + gl;
+        const int row = i / kPatchDwords, dw = i - row * kPatchDwords;
+        staged[t] = __builtin_amdgcn_raw_buffer_load_b32(bplane, first_al + __mul24(row, step) + 4 * dw, 0, 0); // past row 36: unused
+    }
 
     // ---- intensity centroid: m_10 = sum u * I, m_01 = sum v * I over the disc ----
+    long long pitch;
+    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
+    const int hq = gl >> 3, q = gl & 7;
+    const u32 wts = 0x03020100u + 0x04040404u * (u32)q; // u + 16 of the dword's four bytes
+    const uint8_t* col = img + (long long)py * pitch + px - 16 + 4 * q;
     int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int v = half == 0 ? gl - kHalfPatch : gl + 1;
-        if (v <= kHalfPatch) {
-            const int d = c_umax[v < 0 ? -v : v];
-            const uint8_t* row = img + (long long)(py + v) * pitch + px - 16;
-            int s0 = 0, s1 = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const u32 w = load_u32_unaligned(row + 4 * q);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int u = 4 * q + b - 16;
-                    const int au = u < 0 ? -u : u;
-                    const int val = au <= d ? (int)((w >> (8 * b)) & 0xFF) : 0;
-                    s0 += val;
-                    s1 += u * val;
-                }
-            }
-            m10 += s1;
-            m01 += v * s0;
-        }
+    for (int i = 0; i < 16; ++i) {
+        const int v = -kHalfPatch + 2 * i + hq; // 16 for the odd half of the last step: empty mask row
+        const int av = v < 0 ? -v : v;
+        const u32 w = load_u32_unaligned(col + (long long)v * pitch) & disc_mask[av][q];
+        const int s0 = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
+        const int s1 = (int)__builtin_amdgcn_udot4(w, wts, 0u, false);
+        m10 += s1 - 16 * s0;
+        m01 += v * s0;
     }
     m10 = group_sum_i32<kKpGroup>(m10);
     m01 = group_sum_i32<kKpGroup>(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
-
-    // ---- rotated BRIEF on the blurred level ----
     const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = trig_cos(arad), sa = trig_sin(arad);
-    const uint8_t* center = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)py * g.pitch + px;
-    const int step = g.pitch;
+
+#pragma unroll
+    for (int t = 0; t < kPatchLoads; ++t) {
+        const int i = t * kKpGroup + gl;
+        if (i < kPatchRows * kPatchDwords) {
+            my_patch[i] = staged[t];
+        }
+    }
+    // the 16 lanes of a group are in one wavefront: their LDS writes are visible to each other
+    // once the wave's own LDS operations have completed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- rotated BRIEF on the staged neighbourhood ----
+    const uint8_t* centre = &patch[grp][0] + kPatchR * (kPatchDwords * 4) + kPatchR + sh;
+    const f32x2 sc = {sa, ca};  // (sin, cos)
+    const f32x2 cs = {ca, -sa}; // (cos, -sin): y * (cos, -sin) added to x * (sin, cos) gives (row, col)
     u32 bits = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int8_t* pp = &c_pattern[(gl * 16 + k) * 4];
-        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int v0 = center[r0 * step + c0];
-        const int v1 = center[r1 * step + c1];
-        bits |= (u32)(v0 < v1) << k;
+        const float4 pt = pat[gl * 17 + k];
+        // row = x * sin + y * cos, col = x * cos - y * sin  (orb_extractor.cc:676-678); the
+        // negated product y * (-sin) equals -(y * sin) exactly, so the subtraction is unchanged
+        const f32x2 rc0 = (f32x2){pt.x, pt.x} * sc + (f32x2){pt.y, pt.y} * cs;
+        const f32x2 rc1 = (f32x2){pt.z, pt.z} * sc + (f32x2){pt.w, pt.w} * cs;
+        const int v0 = centre[__mul24(__float2int_rn(rc0.x), kPatchDwords * 4) + __float2int_rn(rc0.y)];
+        const int v1 = centre[__mul24(__float2int_rn(rc1.x), kPatchDwords * 4) + __float2int_rn(rc1.y)];
+        bits = __builtin_amdgcn_alignbit(bits, (u32)(v0 - v1), 31); // bits << 1 | (v0 < v1)
     }
+    bits = __brev(bits) >> 16; // pair k of the lane at bit k
     reinterpret_cast<unsigned short*>(out_desc + ((long long)frame * cap + oi) * 32)[gl] = (unsigned short)bits;
 
     if (gl < 7) {
@@ -2117,7 +2182,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand_xy.as<u32>(), h->cand_st.as<u32>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
-    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3((p.kp_total_cap + 15) / 16, n_frames), dim3(256), 0, stream,
+    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3(std::max((std::min(p.kp_total_cap, cap) + 15) / 16, 1), n_frames), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
                d_kps, d_desc, d_counts, cap);
     OVS_HIP(hipGetLastError());
