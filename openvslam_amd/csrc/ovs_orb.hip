@@ -419,11 +419,30 @@ constexpr int kTileStride = 72; // bytes per LDS tile row; byte b of a row is im
 // Stage A of the FAST kernel for one strip of four horizontally adjacent pixels: the high-speed
 // rejection test on the four opposite ring pairs (0,8) (2,10) (4,12) (6,14).  A pixel that is a
 // corner at threshold t has, in every opposite pair, at least one pixel darker than v - t, or in
-// every pair at least one brighter than v + t (any arc of 9 covers one pixel of each pair).
-// Returns a 4-bit mask of the pixels that survive.
+// every pair at least one brighter than v + t (any arc of 9 covers one pixel of each pair):
+//   dark   <=>  max over pairs of min(pair)  <  v - t
+//   bright <=>  min over pairs of max(pair)  >  v + t
+// The four pixels are processed as two registers of two u16 lanes ("even" = columns c, c + 2 and
+// "odd" = c + 1, c + 3): every ring operand is one v_perm_b32 that picks its two bytes out of the
+// tile dwords, the rest is v_pk_min/max_u16 and saturating v_pk_sub_u16.
+// Returns dark flags in bits 0..3 and bright flags in bits 4..7 (bit p = pixel c + p).
+typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pk16 pick2(u32 hi, u32 lo, u32 sel) { return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(hi, lo, sel)); }
+__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ pk16 pk_sub_sat(pk16 a, pk16 b) { return __builtin_elementwise_sub_sat(a, b); }
+
+// bit 0 = e.lo != 0, bit 1 = o.lo != 0, bit 2 = e.hi != 0, bit 3 = o.hi != 0
+__device__ __forceinline__ u32 flags4(pk16 e, pk16 o) {
+    const pk16 one = {1, 1};
+    const u32 y = __builtin_bit_cast(u32, pk_min(e, one)) | (__builtin_bit_cast(u32, pk_min(o, one)) << 1);
+    return (y | (y >> 14)) & 0xFu;
+}
+
 __device__ __forceinline__ u32 fast_quick_test4(const uint8_t* tile, int trow, int strip, int t) {
-    // dwords strip, strip + 1, strip + 2 of a tile row hold columns 4 * strip - 4 .. 4 * strip + 7
-    // relative to the first pixel of the strip (byte 4 of the window)
+    // dwords strip, strip + 1, strip + 2 of a tile row hold columns c - 4 .. c + 7 (c = first pixel
+    // of the strip); selector bytes 0..3 address the second v_perm source, 4..7 the first, 0x0c = 0
     const u32* r0 = reinterpret_cast<const u32*>(tile + trow * kTileStride) + strip;
     const u32* rm2 = reinterpret_cast<const u32*>(tile + (trow - 2) * kTileStride) + strip;
     const u32* rp2 = reinterpret_cast<const u32*>(tile + (trow + 2) * kTileStride) + strip;
@@ -432,30 +451,69 @@ __device__ __forceinline__ u32 fast_quick_test4(const uint8_t* tile, int trow, i
     const u32 c0 = r0[0], c1 = r0[1], c2 = r0[2];
     const u32 m0 = rm2[0], m1 = rm2[1], m2 = rm2[2];
     const u32 p0 = rp2[0], p1 = rp2[1], p2 = rp2[2];
-    u32 out = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int v = win_byte(c0, c1, c2, 4 + p);
-        const int lo = v - t, hi = v + t;
-        const int x0 = (int)((dn3 >> (8 * p)) & 0xFF);  // ring 0  (0, +3)
-        const int x8 = (int)((up3 >> (8 * p)) & 0xFF);  // ring 8  (0, -3)
-        const int x2 = win_byte(p0, p1, p2, 4 + p + 2); // ring 2  (+2, +2)
-        const int x10 = win_byte(m0, m1, m2, 4 + p - 2); // ring 10 (-2, -2)
-        const int x4 = win_byte(c0, c1, c2, 4 + p + 3); // ring 4  (+3, 0)
-        const int x12 = win_byte(c0, c1, c2, 4 + p - 3); // ring 12 (-3, 0)
-        const int x6 = win_byte(m0, m1, m2, 4 + p + 2); // ring 6  (+2, -2)
-        const int x14 = win_byte(p0, p1, p2, 4 + p - 2); // ring 14 (-2, +2)
-        const bool dark = ((x0 < lo) | (x8 < lo)) & ((x2 < lo) | (x10 < lo)) & ((x4 < lo) | (x12 < lo)) & ((x6 < lo) | (x14 < lo));
-        const bool bright = ((x0 > hi) | (x8 > hi)) & ((x2 > hi) | (x10 > hi)) & ((x4 > hi) | (x12 > hi)) & ((x6 > hi) | (x14 > hi));
-        out |= (u32)(dark | bright) << p;
+    constexpr u32 kEven = 0x0c020c00u, kOdd = 0x0c030c01u;       // (b0, b2), (b1, b3) of one dword
+    constexpr u32 kB2nB0 = 0x0c040c02u, kB3nB1 = 0x0c050c03u;     // (lo.b2, hi.b0), (lo.b3, hi.b1)
+    const pk16 ve = pick2(c1, c1, kEven), vo = pick2(c1, c1, kOdd);
+    // ring 0 (0, +3) / ring 8 (0, -3)
+    const pk16 x0e = pick2(dn3, dn3, kEven), x0o = pick2(dn3, dn3, kOdd);
+    const pk16 x8e = pick2(up3, up3, kEven), x8o = pick2(up3, up3, kOdd);
+    // ring 4 (+3, 0): columns (c+3, c+5) / (c+4, c+6);  ring 12 (-3, 0): (c-3, c-1) / (c-2, c)
+    const pk16 x4e = pick2(c2, c1, kB3nB1), x4o = pick2(c2, c2, kEven);
+    const pk16 x12e = pick2(c0, c0, kOdd), x12o = pick2(c1, c0, kB2nB0);
+    // ring 2 (+2, +2): (c+2, c+4) / (c+3, c+5) of row +2;  ring 14 (-2, +2): (c-2, c) / (c-1, c+1)
+    const pk16 x2e = pick2(p2, p1, kB2nB0), x2o = pick2(p2, p1, kB3nB1);
+    const pk16 x14e = pick2(p1, p0, kB2nB0), x14o = pick2(p1, p0, kB3nB1);
+    // ring 6 (+2, -2) and ring 10 (-2, -2): the same columns of row -2
+    const pk16 x6e = pick2(m2, m1, kB2nB0), x6o = pick2(m2, m1, kB3nB1);
+    const pk16 x10e = pick2(m1, m0, kB2nB0), x10o = pick2(m1, m0, kB3nB1);
+    const pk16 de = pk_max(pk_max(pk_min(x0e, x8e), pk_min(x2e, x10e)), pk_max(pk_min(x4e, x12e), pk_min(x6e, x14e)));
+    const pk16 dod = pk_max(pk_max(pk_min(x0o, x8o), pk_min(x2o, x10o)), pk_max(pk_min(x4o, x12o), pk_min(x6o, x14o)));
+    const pk16 be = pk_min(pk_min(pk_max(x0e, x8e), pk_max(x2e, x10e)), pk_min(pk_max(x4e, x12e), pk_max(x6e, x14e)));
+    const pk16 bo = pk_min(pk_min(pk_max(x0o, x8o), pk_max(x2o, x10o)), pk_min(pk_max(x4o, x12o), pk_max(x6o, x14o)));
+    const pk16 tt = {(unsigned short)t, (unsigned short)t};
+    // v - D > t  /  B - v > t, as saturating differences
+    const pk16 sde = pk_sub_sat(pk_sub_sat(ve, de), tt), sdo = pk_sub_sat(pk_sub_sat(vo, dod), tt);
+    const pk16 sbe = pk_sub_sat(pk_sub_sat(be, ve), tt), sbo = pk_sub_sat(pk_sub_sat(bo, vo), tt);
+    const u32 any = __builtin_bit_cast(u32, sde) | __builtin_bit_cast(u32, sdo) | __builtin_bit_cast(u32, sbe) | __builtin_bit_cast(u32, sbo);
+    if (any == 0) {
+        return 0;
     }
-    return out;
+    return flags4(sde, sdo) | (flags4(sbe, sbo) << 4);
+}
+
+// One side of the exact score for a pixel that passed the rejection test on that side.  `inv` is 0
+// for the dark side and 0xFF for the bright side (the bright test of x is the dark test of 255 - x).
+// Returns v' - min over the 16 arcs of 9 of the arc maximum, i.e. the largest t + 1 at which the
+// pixel is a corner on this side (or <= 0).
+__device__ __forceinline__ int fast_side_score(const uint8_t* c, int inv) {
+    constexpr int S = kTileStride;
+    int x[16];
+    x[0] = c[3 * S]; x[1] = c[3 * S + 1]; x[2] = c[2 * S + 2]; x[3] = c[S + 3];
+    x[4] = c[3]; x[5] = c[-S + 3]; x[6] = c[-2 * S + 2]; x[7] = c[-3 * S + 1];
+    x[8] = c[-3 * S]; x[9] = c[-3 * S - 1]; x[10] = c[-2 * S - 2]; x[11] = c[-S - 3];
+    x[12] = c[-3]; x[13] = c[S - 3]; x[14] = c[2 * S - 2]; x[15] = c[3 * S - 1];
+    const int v = c[0] ^ inv;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        x[k] ^= inv;
+    }
+    int mx3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mx3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    int lo = 255;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        lo = min(lo, max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
+    }
+    return v - lo;
 }
 
 __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
     __shared__ uint8_t score[66 * 68];
-    __shared__ unsigned short work[4096];
+    __shared__ unsigned short work[4096]; // survivors of the rejection test, one entry per pixel
     __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
     __shared__ int rowbase[65];
     __shared__ int nwork;
@@ -536,33 +594,66 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
             keep32[tid] = 0;
         }
         __syncthreads();
-        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread
+        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread.  Survivors are
+        // appended to the work list by wave-level compaction: one ballot per pixel position gives
+        // every lane its offset (v_mbcnt), one LDS atomic per wave reserves the range.  An item is
+        // row << 6 | column, bit 12 = passed the dark test, bit 13 = passed the bright test.
         const int strip = tid & 15;
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             const int r = (tid >> 4) + 16 * k;
+            u32 m = 0;
             if (r < ih && 4 * strip < iw) {
-                u32 m = fast_quick_test4(tile, r + 3, strip, thr);
-                m &= (1u << min(iw - 4 * strip, 4)) - 1u;
-                while (m) {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    work[atomicAdd(&nwork, 1)] = (unsigned short)((r << 6) | (4 * strip + b));
+                m = fast_quick_test4(tile, r + 3, strip, thr);
+                const u32 valid = (1u << min(iw - 4 * strip, 4)) - 1u;
+                m &= valid | (valid << 4);
+            }
+            const u32 px = (m | (m >> 4)) & 0xFu;
+            const u64 any = __ballot(px != 0);
+            if (any) {
+                u64 bal[4];
+                int cnt = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    bal[b] = __ballot((px >> b) & 1u);
+                    cnt += __popcll(bal[b]);
+                }
+                int base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&nwork, cnt);
+                }
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if ((px >> b) & 1u) {
+                        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[b], 0u));
+                        work[pos] = (unsigned short)((r << 6) | (4 * strip + b) | (((m >> b) & 1u) << 12) | (((m >> (b + 4)) & 1u) << 13));
+                    }
+                    base += __popcll(bal[b]);
                 }
             }
         }
         __syncthreads();
-        // stage B: exact score of the survivors
+        // stage B: exact score of the survivors from the side that passed (a pixel that passed the
+        // test on one side only cannot reach the threshold on the other, so the side score
+        // decides; both sides for the rare pixel that passed both); below the threshold: 0
         const int nw = nwork;
         for (int i = tid; i < nw; i += 256) {
-            const int r = work[i] >> 6, c = work[i] & 63;
-            score[(r + 1) * 68 + c + 1] = (uint8_t)fast_score_9_16(&tile[(r + 3) * kTileStride + c + 4], kTileStride);
+            const u32 item = work[i];
+            const int r = (item >> 6) & 63, c = item & 63;
+            const uint8_t* centre = &tile[(r + 3) * kTileStride + c + 4];
+            int sc = fast_side_score(centre, (item & 0x1000u) ? 0 : 0xFF) - 1;
+            if ((item & 0x3000u) == 0x3000u) {
+                sc = max(sc, fast_side_score(centre, 0xFF) - 1);
+            }
+            score[(r + 1) * 68 + c + 1] = (uint8_t)(sc >= thr ? sc : 0);
         }
         __syncthreads();
         // non-maximum suppression over the survivors (every other pixel scores below the threshold)
         int mykept = 0;
         for (int i = tid; i < nw; i += 256) {
-            const int r = work[i] >> 6, c = work[i] & 63;
+            const u32 item = work[i];
+            const int r = (item >> 6) & 63, c = item & 63;
             const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
             const int sc = sp[0];
             if (sc >= thr) {
@@ -572,8 +663,8 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         if (dy != 0 || dx != 0) {
-                            const int nb = sp[dy * 68 + dx];
-                            m = max(m, nb >= thr ? nb : 0);
+                            const int nbv = sp[dy * 68 + dx];
+                            m = max(m, nbv >= thr ? nbv : 0);
                         }
                     }
                 }
@@ -600,22 +691,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
         return;
     }
 
+    const int n_items = nwork;
     if (s.mask) {
         // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
-#pragma unroll 1
-        for (int chunk = 0; chunk < 16; ++chunk) {
-            const int r = chunk * 4 + wave;
-            const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
-            bool keep = (bits >> lane) & 1ull;
-            if (keep) {
+        for (int i = tid; i < n_items; i += 256) {
+            const u32 item = work[i];
+            const int r = (item >> 6) & 63, c = item & 63;
+            if ((keep32[2 * r + (c >> 5)] >> (c & 31)) & 1u) {
                 const unsigned y = kBorder + ci * kCell + 3 + r;
-                const unsigned x = kBorder + cj * kCell + 3 + lane;
-                keep = !mask_is_zero(s, y, x, g.scale);
-            }
-            const u64 nb = __ballot(keep);
-            if (lane == 0) { // row r is only touched by this wave
-                keep32[2 * r] = (u32)nb;
-                keep32[2 * r + 1] = (u32)(nb >> 32);
+                const unsigned x = kBorder + cj * kCell + 3 + c;
+                if (mask_is_zero(s, y, x, g.scale)) {
+                    atomicAnd(&keep32[2 * r + (c >> 5)], ~(1u << (c & 31)));
+                }
             }
         }
         __syncthreads();
@@ -638,16 +725,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     }
     __syncthreads();
 
+    // raster order: position = keypoints in the rows above + kept pixels to the left in the row
     u32* out = slots + out_cell * kSlotsPerCell;
-#pragma unroll 1
-    for (int chunk = 0; chunk < 16; ++chunk) {
-        const int r = chunk * 4 + wave;
+    for (int i = tid; i < n_items; i += 256) {
+        const u32 item = work[i];
+        const int r = (item >> 6) & 63, c = item & 63;
         const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
-        if ((bits >> lane) & 1ull) {
-            const int pos = rowbase[r] + __popcll(bits & ((1ull << lane) - 1ull));
-            const u32 x = cj * kCell + 3 + lane; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
+        if ((bits >> c) & 1ull) {
+            const int pos = rowbase[r] + __popcll(bits & ((1ull << c) - 1ull));
+            const u32 x = cj * kCell + 3 + c; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
             const u32 y = ci * kCell + 3 + r;
-            out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + lane + 1] << 24);
+            out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + c + 1] << 24);
         }
     }
     if (tid == 0) {
