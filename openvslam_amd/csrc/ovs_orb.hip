@@ -1046,7 +1046,6 @@ __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t
 // response << 24 | (2^24 - 1 - original index)).
 // -------------------------------------------------------------------------------------------------
 constexpr u32 kLeaf = 0x80000000u; // is_leaf_node_ (only set by initialize_nodes, orb_extractor.cc:545)
-constexpr u32 kPool = 0x40000000u; // member of the pool being processed in the current fill-up pass
 constexpr u32 kProc = 0x20000000u; // split in the current fill-up pass
 constexpr u32 kCnt = 0x00FFFFFFu;
 
@@ -1109,21 +1108,48 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
     return (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
 }
 
+// Candidate record: x | y << 16, response << 24 | current node id.
+// Every pass over the candidates is latency bound (global loads feeding LDS atomics), and the
+// largest level of a frame is the critical path of the whole launch, so the passes are kept few
+// and deep: moving the candidates to their child nodes and voting into the child counters of the
+// NEXT sweep are one pass (the counters are double buffered), and each thread issues four loads
+// before it touches the first result.
+template <typename F>
+__device__ __forceinline__ void for_each_candidate(uint2* __restrict__ cand, int N, F&& f) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i0 = tid; i0 < N; i0 += 4 * nt) {
+        uint2 cd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            cd[u] = cand[min(i, N - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nt;
+            if (i < N) {
+                f(i, cd[u]);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* __restrict__ slots, const u32* __restrict__ cell_counts,
-                                                         u32* __restrict__ cand_xy, u32* __restrict__ cand_st,
+                                                         uint2* __restrict__ cand_all,
                                                          u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count) {
     extern __shared__ u32 smem[];
     const int level = blockIdx.x, frame = blockIdx.y;
     const level_geom& g = p.lv[level];
-    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+    const int tid = threadIdx.x, nt = blockDim.x;
     const int ncap = p.max_ncap;
 
     short4* nb_cur = reinterpret_cast<short4*>(smem);
     short4* nb_nxt = nb_cur + ncap;
     u32* nc_cur = reinterpret_cast<u32*>(nb_nxt + ncap);
     u32* nc_nxt = nc_cur + ncap;
-    u32* cc = nc_nxt + ncap; // 4 * ncap child counters, later child ids
-    u32* t0 = cc + 4 * ncap;
+    u32* cc = nc_nxt + ncap;   // 4 * ncap child counters of the current list, later child ids
+    u32* cc2 = cc + 4 * ncap;  // the same for the list being built
+    u32* t0 = cc2 + 4 * ncap;
     u32* t1 = t0 + ncap;
     u32* t2 = t1 + ncap;
     u32* t3 = t2 + ncap;
@@ -1133,8 +1159,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
 
     const int ncells = g.cells_x * g.cells_y;
     const long long cell0 = (long long)frame * p.total_cells + g.cell_base;
-    u32* cxy = cand_xy + frame * p.frame_cand_cap + g.cand_base;
-    u32* cst = cand_st + frame * p.frame_cand_cap + g.cand_base;
+    uint2* cand = cand_all + frame * p.frame_cand_cap + g.cand_base;
     const int quota = g.quota;
 
     for (int c = tid; c < ncells; c += nt) {
@@ -1149,21 +1174,61 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     for (int q = tid; q < n0; q += nt) {
         t0[q] = 0;
     }
+    // Initial node of a keypoint (orb_extractor.cc:528-535): column (unsigned)(pt.x / delta_x) in
+    // double precision.  The quotient is monotone in the integer pt.x, so column k starts at the
+    // smallest x whose quotient reaches k; those few thresholds are found once with the same
+    // division and the per-candidate work becomes integer compares.  (t2 / t3 hold them: the
+    // node arrays have at least 4 * nx * ny + 8 entries.)
+    u32* thx = t2;
+    u32* thy = t3;
+    for (int k = tid; k < g.nx + g.ny; k += nt) {
+        const bool is_x = k < g.nx;
+        const int kk = is_x ? k : k - g.nx;
+        const double delta = is_x ? g.delta_x : g.delta_y;
+        int x = max((int)((double)kk * delta) - 2, 0);
+        while ((unsigned)((double)(float)x / delta) < (unsigned)kk) {
+            ++x;
+        }
+        (is_x ? thx : thy)[kk] = (u32)x; // threshold 0 is 0
+    }
     __syncthreads();
 
-    // dense candidates in the reference's order + initial node of each (orb_extractor.cc:528-535)
-    for (int c = wave; c < ncells; c += nwaves) {
-        const int base = cellpref[c], cnt = cellpref[c + 1] - base;
-        const u32* src = slots + (cell0 + c) * kSlotsPerCell;
-        for (int e = lane; e < cnt; e += 64) {
-            const u32 v = src[e];
-            const u32 x = v & 0xFFFu, y = (v >> 12) & 0xFFFu, r = v >> 24;
-            const unsigned ix = (unsigned)((double)(float)x / g.delta_x);
-            const unsigned iy = (unsigned)((double)(float)y / g.delta_y);
-            const u32 ni = min(ix + iy * (unsigned)g.nx, (unsigned)(n0 - 1));
-            cxy[base + e] = x | (y << 16);
-            cst[base + e] = (r << 24) | ni;
-            atomicAdd(&t0[ni], 1u);
+    // dense candidates in the reference's order: cells row-major, raster order inside a cell
+    for (int i0 = tid; i0 < N; i0 += 4 * nt) {
+        u32 v[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * nt, N - 1);
+            idx[u] = i;
+            // cell of candidate i: last c with cellpref[c] <= i
+            int lo = 0, hi = ncells - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if ((int)cellpref[mid] <= i) {
+                    lo = mid;
+                }
+                else {
+                    hi = mid - 1;
+                }
+            }
+            v[u] = slots[(cell0 + lo) * kSlotsPerCell + (i - (int)cellpref[lo])];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * nt < N) {
+                const u32 x = v[u] & 0xFFFu, y = (v[u] >> 12) & 0xFFFu, r = v[u] >> 24;
+                u32 ix = 0, iy = 0;
+                for (int k = 1; k < g.nx; ++k) {
+                    ix += x >= thx[k];
+                }
+                for (int k = 1; k < g.ny; ++k) {
+                    iy += y >= thy[k];
+                }
+                const u32 ni = min(ix + iy * (unsigned)g.nx, (unsigned)(n0 - 1));
+                cand[idx[u]] = make_uint2(x | (y << 16), (r << 24) | ni);
+                atomicAdd(&t0[ni], 1u);
+            }
         }
     }
     __syncthreads();
@@ -1185,11 +1250,18 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             nc_cur[t1[q]] = cnt | (cnt == 1 ? kLeaf : 0u);
         }
     }
-    __syncthreads();
-    for (int i = tid; i < N; i += nt) {
-        const u32 st = cst[i];
-        cst[i] = (st & 0xFF000000u) | t1[st & kCnt];
+    for (int i = tid; i < 4 * S; i += nt) {
+        cc[i] = 0;
     }
+    __syncthreads();
+    // compact node ids + votes for the first sweep
+    for_each_candidate(cand, N, [&](int i, uint2 cd) {
+        const u32 n = t1[cd.y & kCnt];
+        cand[i].y = (cd.y & 0xFF000000u) | n;
+        if (!(nc_cur[n] & kLeaf)) {
+            atomicAdd(&cc[4 * n + child_of(nb_cur[n], cd.x & 0xFFFF, cd.x >> 16)], 1u);
+        }
+    });
     __syncthreads();
 
     bool filled = false;
@@ -1197,23 +1269,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     int front = 0; // number of freshly created nodes at the head of the list
 
     // ---- orb_extractor.cc:411-442: split every non-leaf node per sweep -------------------------
+    // invariant at the top: cc holds the child counts of every non-leaf node of the current list
     while (true) {
         const int prev = S;
-        for (int i = tid; i < 4 * S; i += nt) {
-            cc[i] = 0;
-        }
         if (tid == 0) {
             sh[0] = 0;
         }
-        __syncthreads();
-        for (int i = tid; i < N; i += nt) {
-            const u32 n = cst[i] & kCnt;
-            if (!(nc_cur[n] & kLeaf)) {
-                const u32 xy = cxy[i];
-                atomicAdd(&cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)], 1u);
-            }
-        }
-        __syncthreads();
         for (int q = tid; q < S; q += nt) {
             const bool leaf = nc_cur[q] & kLeaf;
             t0[q] = leaf ? 0 : nonzero4(&cc[4 * q]);
@@ -1255,20 +1316,20 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         if (local_pool) {
             atomicAdd(&sh[0], local_pool);
         }
-        __syncthreads();
-        for (int i = tid; i < N; i += nt) {
-            const u32 st = cst[i];
-            const u32 n = st & kCnt;
-            u32 nn;
-            if (nc_cur[n] & kLeaf) {
-                nn = cc[4 * n];
-            }
-            else {
-                const u32 xy = cxy[i];
-                nn = cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)];
-            }
-            cst[i] = (st & 0xFF000000u) | nn;
+        for (int i = tid; i < 4 * Snew; i += nt) {
+            cc2[i] = 0;
         }
+        __syncthreads();
+        // move every candidate to its child and vote for the next split of that child
+        for_each_candidate(cand, N, [&](int i, uint2 cd) {
+            const u32 n = cd.y & kCnt;
+            const int x = cd.x & 0xFFFF, y = cd.x >> 16;
+            const u32 nn = (nc_cur[n] & kLeaf) ? cc[4 * n] : cc[4 * n + child_of(nb_cur[n], x, y)];
+            cand[i].y = (cd.y & 0xFF000000u) | nn;
+            if (!(nc_nxt[nn] & kLeaf)) {
+                atomicAdd(&cc2[4 * nn + child_of(nb_nxt[nn], x, y)], 1u);
+            }
+        });
         const int pool = (int)sh[0];
         __syncthreads();
         {
@@ -1278,6 +1339,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             u32* tc = nc_cur;
             nc_cur = nc_nxt;
             nc_nxt = tc;
+            tc = cc;
+            cc = cc2;
+            cc2 = tc;
         }
         S = Snew;
         front = C;
@@ -1292,10 +1356,14 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     }
 
     // ---- orb_extractor.cc:444-472: split the fullest nodes first until the quota is reached ----
+    // cc still holds the child counts of every non-leaf node, in particular of the pool
     while (!filled && !overflow) {
         const int prev = S;
         for (int q = tid; q < front; q += nt) {
             t0[q] = (nc_cur[q] & kCnt) > 1;
+        }
+        if (tid == 0) {
+            sh[1] = 0x7FFFFFFFu;
         }
         __syncthreads();
         const int P = (int)block_excl_scan(t0, front, red);
@@ -1308,35 +1376,20 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             }
         }
         __syncthreads();
-        // stable sort by count descending (rank by counting; the pool is at most a few hundred nodes)
+        // stable sort by count descending (rank by counting over a dense copy of the counts; the
+        // pool is at most a few hundred nodes)
         for (int k = tid; k < P; k += nt) {
-            const u32 qk = t1[k];
-            const u32 ck = nc_cur[qk] & kCnt;
+            t3[k] = nc_cur[t1[k]] & kCnt;
+        }
+        __syncthreads();
+        for (int k = tid; k < P; k += nt) {
+            const u32 ck = t3[k];
             int rank = 0;
             for (int j = 0; j < P; ++j) {
-                const u32 cj = nc_cur[t1[j]] & kCnt;
+                const u32 cj = t3[j];
                 rank += (cj > ck) || (cj == ck && j < k);
             }
-            t2[rank] = qk;
-            cc[4 * qk] = 0;
-            cc[4 * qk + 1] = 0;
-            cc[4 * qk + 2] = 0;
-            cc[4 * qk + 3] = 0;
-        }
-        if (tid == 0) {
-            sh[1] = P - 1;
-        }
-        __syncthreads();
-        for (int k = tid; k < P; k += nt) {
-            nc_cur[t2[k]] |= kPool;
-        }
-        __syncthreads();
-        for (int i = tid; i < N; i += nt) {
-            const u32 n = cst[i] & kCnt;
-            if (nc_cur[n] & kPool) {
-                const u32 xy = cxy[i];
-                atomicAdd(&cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)], 1u);
-            }
+            t2[rank] = t1[k];
         }
         __syncthreads();
         for (int k = tid; k < P; k += nt) {
@@ -1352,7 +1405,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             }
         }
         __syncthreads();
-        const int kstar = (int)sh[1];
+        const int kstar = min((int)sh[1], P - 1);
         const int Cn = (int)t0[kstar] + nonzero4(&cc[4 * t2[kstar]]);
         const int Snew = Cn + S - (kstar + 1);
         const bool filled_now = quota <= Snew;
@@ -1389,23 +1442,22 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             if (!(nc_cur[q] & kProc)) {
                 const int qn = Cn + (int)t3[q];
                 nb_nxt[qn] = nb_cur[q];
-                nc_nxt[qn] = nc_cur[q] & ~kPool;
+                nc_nxt[qn] = nc_cur[q];
             }
+        }
+        for (int i = tid; i < 4 * Snew; i += nt) {
+            cc2[i] = 0;
         }
         __syncthreads();
-        for (int i = tid; i < N; i += nt) {
-            const u32 st = cst[i];
-            const u32 n = st & kCnt;
-            u32 nn;
-            if (nc_cur[n] & kProc) {
-                const u32 xy = cxy[i];
-                nn = cc[4 * n + child_of(nb_cur[n], xy & 0xFFFF, xy >> 16)];
+        for_each_candidate(cand, N, [&](int i, uint2 cd) {
+            const u32 n = cd.y & kCnt;
+            const int x = cd.x & 0xFFFF, y = cd.x >> 16;
+            const u32 nn = (nc_cur[n] & kProc) ? cc[4 * n + child_of(nb_cur[n], x, y)] : Cn + t3[n];
+            cand[i].y = (cd.y & 0xFF000000u) | nn;
+            if (!(nc_nxt[nn] & kLeaf)) {
+                atomicAdd(&cc2[4 * nn + child_of(nb_nxt[nn], x, y)], 1u);
             }
-            else {
-                nn = Cn + t3[n];
-            }
-            cst[i] = (st & 0xFF000000u) | nn;
-        }
+        });
         __syncthreads();
         {
             short4* tb = nb_cur;
@@ -1414,6 +1466,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             u32* tc = nc_cur;
             nc_cur = nc_nxt;
             nc_nxt = tc;
+            tc = cc;
+            cc = cc2;
+            cc2 = tc;
         }
         S = Snew;
         front = Cn;
@@ -1430,20 +1485,20 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     }
 
     // ---- orb_extractor.cc:568-590: first keypoint of maximum response per node ------------------
+    __syncthreads();
     for (int q = tid; q < S; q += nt) {
         cc[q] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < N; i += nt) {
-        const u32 st = cst[i];
-        atomicMax(&cc[st & kCnt], (st & 0xFF000000u) | (0xFFFFFFu - (u32)i));
-    }
+    for_each_candidate(cand, N, [&](int i, uint2 cd) {
+        atomicMax(&cc[cd.y & kCnt], (cd.y & 0xFF000000u) | (0xFFFFFFu - (u32)i));
+    });
     __syncthreads();
     const long long ob = (long long)frame * p.kp_total_cap + g.kp_base;
     for (int q = tid; q < S; q += nt) {
         const u32 v = cc[q];
         const u32 i = 0xFFFFFFu - (v & 0xFFFFFFu);
-        lvl_xy[ob + q] = cxy[i];
+        lvl_xy[ob + q] = cand[i].x;
         lvl_resp[ob + q] = (uint8_t)(v >> 24);
     }
     if (tid == 0) {
@@ -1753,7 +1808,7 @@ struct ovs_orb {
 
     // batch-capacity dependent buffers
     int batch_cap = 0;
-    ovs::dev_buffer pyr, blur, slots, cell_counts, cand_xy, cand_st, lvl_xy, lvl_resp, lvl_count;
+    ovs::dev_buffer pyr, blur, slots, cell_counts, cand, lvl_xy, lvl_resp, lvl_count;
     // staging for the single-frame host entry point
     ovs::dev_buffer st_img, st_mask, st_kps, st_desc, st_count;
     hipStream_t own_stream = nullptr;
@@ -1878,8 +1933,8 @@ bool is_area_fast_2x(int sw, int sh, int dw, int dh) {
 }
 
 size_t quadtree_lds_bytes(const plan_dev& p) {
-    // nb x2 (8 B), nc x2 (4 B), cc (16 B), t0..t3 (16 B) per node + cell prefix + scratch
-    return static_cast<size_t>(p.max_ncap) * (16 + 8 + 16 + 16) + static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
+    // nb x2 (8 B), nc x2 (4 B), cc x2 (16 B), t0..t3 (16 B) per node + cell prefix + scratch
+    return static_cast<size_t>(p.max_ncap) * (16 + 8 + 32 + 16) + static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
 }
 
 int build_plan(ovs_orb* h, int width, int height) {
@@ -2004,8 +2059,7 @@ int ensure_buffers(ovs_orb* h, int n_frames) {
     if ((rc = h->blur.reserve(B * p.frame_blur_bytes)) != OVS_OK) return rc;
     if ((rc = h->slots.reserve(B * p.total_cells * kSlotsPerCell * sizeof(u32))) != OVS_OK) return rc;
     if ((rc = h->cell_counts.reserve(B * p.total_cells * sizeof(u32))) != OVS_OK) return rc;
-    if ((rc = h->cand_xy.reserve(B * p.frame_cand_cap * sizeof(u32))) != OVS_OK) return rc;
-    if ((rc = h->cand_st.reserve(B * p.frame_cand_cap * sizeof(u32))) != OVS_OK) return rc;
+    if ((rc = h->cand.reserve(B * p.frame_cand_cap * sizeof(uint2))) != OVS_OK) return rc;
     if ((rc = h->lvl_xy.reserve(B * p.kp_total_cap * sizeof(u32))) != OVS_OK) return rc;
     if ((rc = h->lvl_resp.reserve(B * p.kp_total_cap)) != OVS_OK) return rc;
     if ((rc = h->lvl_count.reserve(B * p.num_levels * sizeof(int))) != OVS_OK) return rc;
@@ -2113,7 +2167,7 @@ void ovs_orb_destroy(ovs_orb* h) {
         return;
     }
     ovs::device_guard guard(h->device);
-    for (ovs::dev_buffer* b : {&h->tabs, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand_xy, &h->cand_st,
+    for (ovs::dev_buffer* b : {&h->tabs, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand,
                                &h->lvl_xy, &h->lvl_resp, &h->lvl_count, &h->st_img, &h->st_mask, &h->st_kps, &h->st_desc, &h->st_count}) {
         b->release();
     }
@@ -2268,7 +2322,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     OVS_LAUNCH("k_gauss7", k_gauss7, dim3((p.total_blur_tiles + 3) / 4, n_frames), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>());
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
-               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand_xy.as<u32>(), h->cand_st.as<u32>(),
+               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
     OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3(std::max((std::min(p.kp_total_cap, cap) + 15) / 16, 1), n_frames), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
