@@ -43,6 +43,16 @@ typedef unsigned int u32;
 typedef unsigned long long u64;
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive block ids
+// land on different L2s.  The streaming kernels share cache lines between neighbouring tiles /
+// cells; they are launched as a 1-D grid of 8 * ceil(total / 8) blocks and every XCD walks one
+// contiguous eighth of the logical (frame, tile) space.  Returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_contiguous_block(int total) {
+    const int per = (total + 7) >> 3;
+    const int logical = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    return logical < total ? logical : -1;
+}
+
 struct level_geom {
     int w, h;
     int pitch;            // row pitch of the library-owned planes of this level
@@ -324,12 +334,17 @@ __device__ __forceinline__ void resize_tile(const level_geom& g, const level_geo
     }
 }
 
-__global__ __launch_bounds__(256) void k_resize_rows(plan_dev p, image_src s, const int* __restrict__ tabs, int level, int tiles_x, int tiles) {
+__global__ __launch_bounds__(256) void k_resize_rows(plan_dev p, image_src s, const int* __restrict__ tabs, int level, int tiles_x, int tiles, int n_frames) {
     const level_geom& g = p.lv[level];
     const level_geom& gs = p.lv[level - 1];
-    const int frame = blockIdx.y;
+    const int groups = (tiles + 3) >> 2; // four wave tiles per workgroup
+    const int blk = xcd_contiguous_block(groups * n_frames);
+    if (blk < 0) {
+        return;
+    }
+    const int frame = blk / groups;
     const int lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int t = __builtin_amdgcn_readfirstlane((blk - frame * groups) * 4 + (threadIdx.x >> 6));
     if (t >= tiles) {
         return;
     }
@@ -510,7 +525,7 @@ __device__ __forceinline__ int fast_side_score(const uint8_t* c, int inv) {
     return v - lo;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts) {
+__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts, int n_frames) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
     __shared__ uint8_t score[66 * 68];
     __shared__ unsigned short work[4096]; // survivors of the rejection test, one entry per pixel
@@ -519,8 +534,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     __shared__ int nwork;
     __shared__ int total;
 
-    const int frame = blockIdx.y;
-    int cell = blockIdx.x;
+    const int blk = xcd_contiguous_block(p.total_cells * n_frames);
+    if (blk < 0) {
+        return;
+    }
+    const int frame = blk / p.total_cells;
+    int cell = blk - frame * p.total_cells;
     int level = 0;
 #pragma unroll 1
     for (int l = 1; l < p.num_levels; ++l) {
@@ -993,10 +1012,15 @@ __device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* im
     }
 }
 
-__global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur) {
-    const int frame = blockIdx.y;
+__global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur, int n_frames) {
+    const int groups = (p.total_blur_tiles + 3) >> 2; // four wave tiles per workgroup
+    const int blk = xcd_contiguous_block(groups * n_frames);
+    if (blk < 0) {
+        return;
+    }
+    const int frame = blk / groups;
     const int lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int t = __builtin_amdgcn_readfirstlane((blk - frame * groups) * 4 + (threadIdx.x >> 6));
     if (t >= p.total_blur_tiles) {
         return;
     }
@@ -1617,12 +1641,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
                                                      const u32* __restrict__ lvl_xy, const uint8_t* __restrict__ lvl_resp,
                                                      const int* __restrict__ lvl_count,
                                                      ovs_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                     int* __restrict__ out_counts, int cap) {
+                                                     int* __restrict__ out_counts, int cap, int blocks_per_frame, int n_frames) {
     __shared__ float4 pat[16 * 17];   // (x0, y0, x1, y1) of pair 16 g + k at [17 g + k]
     __shared__ u32 disc_mask[17][8];  // byte masks of a disc row by |v|; row 16 = empty
     __shared__ __attribute__((aligned(16))) uint8_t patch[16][kPatchBytes];
 
-    const int frame = blockIdx.y;
+    const int blk = xcd_contiguous_block(blocks_per_frame * n_frames);
+    if (blk < 0) {
+        return;
+    }
+    const int frame = blk / blocks_per_frame;
+    const int fblk = blk - frame * blocks_per_frame; // block of 16 output slots inside the frame
     const int gl = threadIdx.x & (kKpGroup - 1);
     const int grp = threadIdx.x / kKpGroup;
     // Output slot oi of the frame (level-major concatenation, orb_extractor.cc:120-143) is keypoint
@@ -1639,13 +1668,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
         }
     }
     const int total = __shfl(incl, kKpGroup - 1, kKpGroup);
-    const int oi = blockIdx.x * (256 / kKpGroup) + grp;
+    const int oi = fblk * (256 / kKpGroup) + grp;
     if (oi == 0 && gl == 0) {
         // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
         out_counts[frame] = bad ? (int)0x80000000 : (total > cap ? -total : total);
     }
     const int n_out = bad ? 0 : min(total, cap);
-    if ((int)blockIdx.x * (256 / kKpGroup) >= n_out) {
+    if (fblk * (256 / kKpGroup) >= n_out) {
         return; // the whole workgroup is past the last keypoint (same decision in every thread)
     }
     {
@@ -1931,6 +1960,9 @@ bool is_area_fast_2x(int sw, int sh, int dw, int dh) {
     return std::fabs(scale_x - iscale_x) < DBL_EPSILON && std::fabs(scale_y - iscale_y) < DBL_EPSILON
            && iscale_x == 2 && iscale_y == 2;
 }
+
+// grid size of a kernel that maps its blocks with xcd_contiguous_block()
+unsigned xcd_grid(long long total) { return static_cast<unsigned>(((total + 7) / 8) * 8); }
 
 size_t quadtree_lds_bytes(const plan_dev& p) {
     // nb x2 (8 B), nc x2 (4 B), cc x2 (16 B), t0..t3 (16 B) per node + cell prefix + scratch
@@ -2310,23 +2342,24 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
         const level_geom& g = p.lv[l];
         if (g.resize_rows) {
             const int tiles_x = (g.w + 255) / 256, tiles = tiles_x * ((g.h + kResizeRows - 1) / kResizeRows);
-            OVS_LAUNCH("k_resize_rows", k_resize_rows, dim3((tiles + 3) / 4, n_frames), dim3(256), 0, stream, p, src, h->tabs.as<int>(), l, tiles_x, tiles);
+            OVS_LAUNCH("k_resize_rows", k_resize_rows, dim3(xcd_grid((tiles + 3) / 4 * n_frames)), dim3(256), 0, stream, p, src, h->tabs.as<int>(), l, tiles_x, tiles, n_frames);
         }
         else {
             dim3 grid((g.w + 255) / 256, (g.h + 3) / 4, n_frames), block(64, 4, 1);
             OVS_LAUNCH("k_resize_linear", k_resize_linear, grid, block, 0, stream, p, src, h->tabs.as<int>(), l);
         }
     }
-    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(p.total_cells, n_frames), dim3(256), 0, stream,
-               p, src, h->slots.as<u32>(), h->cell_counts.as<u32>());
-    OVS_LAUNCH("k_gauss7", k_gauss7, dim3((p.total_blur_tiles + 3) / 4, n_frames), dim3(256), 0, stream,
-               p, src, h->blur.as<uint8_t>());
+    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells * n_frames)), dim3(256), 0, stream,
+               p, src, h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
+    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, stream,
+               p, src, h->blur.as<uint8_t>(), n_frames);
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
-    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3(std::max((std::min(p.kp_total_cap, cap) + 15) / 16, 1), n_frames), dim3(256), 0, stream,
+    const int od_blocks = std::max((std::min(p.kp_total_cap, cap) + 15) / 16, 1);
+    OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3(xcd_grid(static_cast<long long>(od_blocks) * n_frames)), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
-               d_kps, d_desc, d_counts, cap);
+               d_kps, d_desc, d_counts, cap, od_blocks, n_frames);
     OVS_HIP(hipGetLastError());
 
     h->last_img0 = d_imgs;
