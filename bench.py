@@ -77,9 +77,10 @@ def make_frames_on_device(n_frames, device, seed=0xC0FFEE):
 class Pipeline:
     """Extract + match of one resident batch through the C ABI (device pointers, one stream)."""
 
-    def __init__(self, device_index, n_frames):
+    def __init__(self, device_index, n_frames, stream=None):
         self.dev = torch.device("cuda", device_index)
         self.n_frames = n_frames
+        self.stream = stream
         self.ext = orb_extractor(orb_params(MAX_KP, SCALE, LEVELS, 20, 7), device=device_index)
         self.cap = self.ext.keypoint_capacity(WIDTH, HEIGHT)
         self.kps = torch.zeros((n_frames, self.cap, 7), dtype=torch.float32, device=self.dev)
@@ -95,6 +96,13 @@ class Pipeline:
         self.device_index = device_index
 
     def step(self, frames):
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._step(frames)
+        else:
+            self._step(frames)
+
+    def _step(self, frames):
         L = _lib.lib()
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.ext.extract_batch_dev(frames.data_ptr(), self.n_frames, WIDTH, HEIGHT, WIDTH, WIDTH * HEIGHT,
@@ -198,6 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames matched per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="sub-batches in flight on separate HIP streams (each re-extracts one halo frame)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -217,18 +226,35 @@ def main():
     n_frames = args.batch + 1
     frames = make_frames_on_device(n_frames, dev, seed=0xC0FFEE + rank)
     pipe = Pipeline(local_rank, n_frames)
+    if args.streams > 1:
+        # the batch as `streams` contiguous sub-batches, each with its own extractor handle, buffers and
+        # stream; sub-batch k starts with the last frame of sub-batch k - 1 as its halo
+        per = args.batch // args.streams
+        assert per * args.streams == args.batch
+        subs = [Pipeline(local_rank, per + 1, torch.cuda.Stream(dev)) for _ in range(args.streams)]
+
+        class Multi:
+            counts = property(lambda self_: torch.cat([sp.counts[1:] for sp in subs]))
+            num_matches = property(lambda self_: torch.cat([subs[0].num_matches[:1] * 0] + [sp.num_matches[1:] for sp in subs]))
+
+            def step(self_, fr):
+                for k, sp in enumerate(subs):
+                    sp.step(fr[k * per:k * per + per + 1])
+
+        multi = Multi()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    timed = multi if args.streams > 1 else pipe
     for _ in range(args.warmup):
-        pipe.step(frames)
+        timed.step(frames)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step(frames)
+        timed.step(frames)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
     barrier()
@@ -237,8 +263,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    counts = pipe.counts.cpu().numpy()
-    nm = pipe.num_matches.cpu().numpy()
+    counts = timed.counts.cpu().numpy()
+    nm = timed.num_matches.cpu().numpy()
     value = args.batch * args.steps * world / elapsed
 
     out = {

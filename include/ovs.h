@@ -400,6 +400,11 @@ int ovs_knn2_merge_dev(const ovs_knn2* d_lists, int n_lists, int nq, ovs_knn2* d
 /* Batched extract + match on resident frames (offline sequences)                             */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
+ * at a time (its buffers belong to the stream of the last call), while the matcher entry points
+ * keep their scratch memory per (host thread, device, stream), so independent batches may be in
+ * flight on several streams at once. */
+
 /* For every frame f >= 1 of the batch last extracted with ovs_orb_extract_batch_dev (outputs
  * d_kps/d_desc/d_counts as written by that call), runs projection::match_current_and_last_frames
  * (projection.cc:84-209) with frame f as `curr` and frame f-1 as `last`, every last keypoint

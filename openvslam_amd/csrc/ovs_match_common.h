@@ -97,25 +97,30 @@ __device__ __forceinline__ int angle_bin(float delta_angle) {
 }
 
 // ---- host plumbing ----------------------------------------------------------------------------------
-// One stream and one growable scratch arena per (host thread, device): the matcher entry points
-// keep no other state, so they can be called from the tracking, mapping and global optimisation
-// threads concurrently.
+// One growable scratch arena per (host thread, device, caller stream), plus one internal stream per
+// (host thread, device) for the entry points that take host buffers.  The matcher entry points keep
+// no other state, so they can be called from the tracking, mapping and global optimisation threads
+// concurrently, and the device-pointer entry points may be in flight on several caller streams at
+// once: work queued on one stream never shares scratch memory with work queued on another.
 struct thread_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t key = nullptr;    // caller stream this context belongs to; nullptr = internal stream
+    hipStream_t stream = nullptr; // internal stream (key == nullptr only)
     ovs::dev_buffer arena;
 };
 
-inline thread_ctx* ctx_for(int device) {
-    static thread_local std::vector<thread_ctx> ctxs;
-    for (auto& c : ctxs) {
-        if (c.device == device) {
-            return &c;
+inline thread_ctx* ctx_for(int device, hipStream_t key = nullptr) {
+    static thread_local std::vector<thread_ctx*> ctxs; // pointers stay valid when the vector grows
+    for (thread_ctx* c : ctxs) {
+        if (c->device == device && c->key == key) {
+            return c;
         }
     }
-    ctxs.emplace_back();
-    ctxs.back().device = device;
-    return &ctxs.back();
+    thread_ctx* c = new thread_ctx;
+    c->device = device;
+    c->key = key;
+    ctxs.push_back(c);
+    return c;
 }
 
 struct carver {

@@ -1654,8 +1654,8 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
         return rc;
     }
     ovs::device_guard guard(device);
-    thread_ctx* ctx = ctx_for(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
+    thread_ctx* ctx = ctx_for(device, st);
     const size_t F = n_frames, fc = F * cap;
     const size_t total = al(64 * 4) + al(F * (ncell + 1) * 4) + al(fc * 4) * 5 + al(fc * 16) + al(fc * 32) + al(fc) + al(fc * kTopK * 8)
                          + al(256) + al(F * sizeof(proj_problem));
