@@ -26,6 +26,12 @@ def lib():
         if not LIB_PATH.exists():
             raise ImportError("%s is missing: build it with `make -C openvslam_amd/csrc` "
                               "(the HIP extension is mandatory, there is no CPU path)" % LIB_PATH)
+        try:
+            # PyTorch-ROCm ships its own copy of the HIP runtime; when both live in one process the
+            # copy torch loads must come first or torch later sees no devices
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(str(LIB_PATH))
         _declare(_lib)
     return _lib

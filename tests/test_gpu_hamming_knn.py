@@ -156,3 +156,68 @@ def test_sharded_search_equals_whole_database():
     _lib.check(_lib.lib().ovs_knn2_merge_dev(d_lists.data_ptr(), 4, len(q), d_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert d_out.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_full_size_database_shards_find_planted_neighbours():
+    """The relocalisation configuration at full size: 2000 queries against 10 000 keyframes x 2000
+    descriptors (640 MB) held as 8 shards of 1250 keyframes; 25 % of the queries are planted
+    near-duplicates (<= 30 flipped bits) of known database rows.  Checked through properties (the
+    planted row is the reported nearest row at the planted distance; the merged result is
+    independent of the shard order) and, for a sample of queries, against the oracle's scan of
+    the whole database."""
+    import torch
+    from openvslam_amd import dist as ovd
+    rng = np.random.default_rng(2024)
+    n_shards, rows_per_shard, nq = 8, 1250 * 2000, 2000
+    n_rows = n_shards * rows_per_shard
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    planted = rng.choice(nq, nq // 4, replace=False)
+    planted_rows = rng.integers(0, n_rows, len(planted))
+    flips = rng.integers(0, 31, len(planted))
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.ovs_desc_db_create(0, C.byref(h)))
+    lists = np.zeros((n_shards, nq), dtype=A.KNN2_DTYPE)
+    sample = np.concatenate([planted[:6], np.setdiff1d(np.arange(nq), planted)[:6]])
+    want_sample = np.zeros((n_shards, len(sample)), dtype=A.KNN2_DTYPE)
+    qs = np.ascontiguousarray(q[sample])
+    try:
+        for s in range(n_shards):
+            # shard s is generated from its own seed; planted rows are overwritten after generation
+            shard = np.random.default_rng(1000 + s).integers(0, 256, (rows_per_shard, 32), dtype=np.uint8)
+            first = s * rows_per_shard
+            for qi, row, nf in zip(planted, planted_rows, flips):
+                if first <= row < first + rows_per_shard:
+                    d = shard[row - first].copy()
+                    for b in np.random.default_rng(int(row)).choice(256, nf, replace=False):
+                        d[b >> 3] ^= np.uint8(1 << (b & 7))
+                    q[qi] = d
+            del shard
+        # second pass: search every shard with the final queries (regenerated from the same seeds)
+        qs = np.ascontiguousarray(q[sample])
+        for s in range(n_shards):
+            shard = np.random.default_rng(1000 + s).integers(0, 256, (rows_per_shard, 32), dtype=np.uint8)
+            first = s * rows_per_shard
+            _lib.check(L.ovs_desc_db_upload(h, A.ptr(shard, A.u8p), rows_per_shard, first))
+            _lib.check(L.ovs_desc_db_search(h, A.ptr(q, A.u8p), nq, A.ptr(lists[s], A.knn2p)))
+            oracle.check(oracle.lib().ovo_knn2_search(A.ptr(shard, A.u8p), rows_per_shard, first, A.ptr(qs, A.u8p), len(sample),
+                                                      A.ptr(want_sample[s], A.knn2p)))
+            del shard
+    finally:
+        L.ovs_desc_db_destroy(h)
+    merged = ovd.merge_topk_host(lists, n_shards, nq)
+    # planted neighbours: nearest row and distance as planted (random 256-bit rows are ~128 apart)
+    assert np.array_equal(merged["row"][planted, 0], planted_rows)
+    assert np.array_equal(merged["dist"][planted, 0], flips.astype(np.uint32))
+    assert merged["dist"][:, 1].min() > 60 and merged["dist"][np.setdiff1d(np.arange(nq), planted), 0].min() > 60
+    # shard order does not matter; device merge equals host merge
+    perm = rng.permutation(n_shards)
+    assert ovd.merge_topk_host(np.ascontiguousarray(lists[perm]), n_shards, nq).tobytes() == merged.tobytes()
+    d_lists = torch.from_numpy(lists.view(np.uint8).reshape(-1)).cuda()
+    d_out = torch.zeros(nq * 24, dtype=torch.uint8, device="cuda")
+    _lib.check(L.ovs_knn2_merge_dev(d_lists.data_ptr(), n_shards, nq, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert d_out.cpu().numpy().tobytes() == merged.tobytes()
+    # oracle on the sample: per-shard results and the merge of the oracle's own lists
+    want = ovd.merge_topk_host(want_sample, n_shards, len(sample))
+    assert merged[sample].tobytes() == want.tobytes()

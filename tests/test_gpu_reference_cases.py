@@ -60,3 +60,19 @@ def test_committed_golden_outputs():
     assert k0.tobytes() == g["kps0"].tobytes() and np.array_equal(d0, g["desc0"])
     k1, d1 = ext.extract(g["frame1"])
     assert k1.tobytes() == g["kps1"].tobytes() and np.array_equal(d1, g["desc1"])
+
+
+def test_equirectangular_4000_keypoints_with_tutorial_masks():
+    """The 1920x960 THETA-style configuration: 4000 keypoints, the rectangle masks of
+    docs/simple_tutorial.rst:297-301, and an image mask on top (bit-exact against the oracle)."""
+    img = refdata.equirectangular(1)
+    h, w = img.shape
+    rects = [(0.0, 1.0, 0.0, 0.1), (0.0, 1.0, 0.84, 1.0), (0.0, 0.2, 0.7, 1.0), (0.8, 1.0, 0.7, 1.0)]
+    k = both(img, max_num_keypts=4000, mask_rects=rects)
+    assert len(k) >= 4000
+    assert k["y"].min() >= int(0.1 * h) and k["y"].max() <= int(0.84 * h) + 1
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = ((xx - w // 2) ** 2 + (yy - h // 2) ** 2 > 200 ** 2).astype(np.uint8) * 255
+    k = both(img, mask, max_num_keypts=4000)   # an image mask overrides the rectangle mask
+    assert len(k) >= 4000
+    assert np.all((k["x"] - w // 2) ** 2 + (k["y"] - h // 2) ** 2 >= 199 ** 2)
