@@ -20,6 +20,8 @@
 
 #include "ovs.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -377,6 +379,130 @@ public:
         }
         return num;
     }
+
+    // projection.cc:211-313
+    template <class Frame, class Keyframe, class LandmarkSet>
+    unsigned int match_frame_and_keyframe(Frame& curr_frm, Keyframe* keyfrm, const LandmarkSet& already_matched_lms,
+                                          const float margin, const unsigned int hamm_dist_thr) const {
+        const auto rot_cw = curr_frm.cam_pose_cw_.template block<3, 3>(0, 0).eval();
+        const auto trans_cw = curr_frm.cam_pose_cw_.template block<3, 1>(0, 3).eval();
+        const auto cam_center = (-rot_cw.transpose() * trans_cw).eval();
+        const auto landmarks = keyfrm->get_landmarks();
+        typedef typename std::remove_reference<decltype(*landmarks.at(0))>::type landmark_t;
+
+        frame_arrays fa;
+        flatten_frame(curr_frm, fa);
+        query_arrays qa;
+        qa.reserve(landmarks.size());
+        std::vector<landmark_t*> query_lms;
+        for (unsigned int idx = 0; idx < landmarks.size(); idx++) {
+            auto* lm = landmarks.at(idx);
+            if (!lm || lm->will_be_erased() || already_matched_lms.count(lm)) {
+                continue;
+            }
+            const auto pos_w = lm->get_pos_in_world();
+            typename std::remove_cv<typename std::remove_reference<decltype(lm->reproj_in_tracking_)>::type>::type reproj; // Vec2_t
+            float x_right;
+            if (!curr_frm.camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) {
+                continue;
+            }
+            const auto cam_to_lm_vec = (pos_w - cam_center).eval();
+            const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+            if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) {
+                continue;
+            }
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, &curr_frm);
+            const auto desc = lm->get_descriptor();
+            qa.push(reproj(0), reproj(1), x_right, static_cast<int>(pred_scale_level), keyfrm->undist_keypts_.at(idx).angle, desc, true, true);
+            query_lms.push_back(lm);
+        }
+        // candidates are skipped when curr_frm.landmarks_.at(i) is non-null (projection.cc:275)
+        std::vector<uint8_t> occ(curr_frm.landmarks_.size(), 0);
+        for (size_t i = 0; i < occ.size(); ++i) {
+            occ[i] = curr_frm.landmarks_[i] ? 1 : 0;
+        }
+        std::vector<int32_t> matched(occ.size(), -1);
+        uint32_t num = 0;
+        check(ovs_match_frame_and_keyframe(&fa.view, qa.finish(), occ.data(), margin, hamm_dist_thr, check_orientation_ ? 1 : 0,
+                                           matched.data(), &num, device_));
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                curr_frm.landmarks_.at(i) = query_lms.at(matched[i]);
+            }
+            else if (matched[i] == -2) {
+                curr_frm.landmarks_.at(i) = nullptr;
+            }
+        }
+        return num;
+    }
+
+    // projection.cc:315-413
+    template <class Keyframe, class Mat44, class Landmark>
+    unsigned int match_by_Sim3_transform(Keyframe* keyfrm, const Mat44& Sim3_cw, const std::vector<Landmark*>& landmarks,
+                                         std::vector<Landmark*>& matched_lms_in_keyfrm, const float margin) const {
+        const auto s_rot_cw = Sim3_cw.template block<3, 3>(0, 0).eval();
+        const auto row0 = s_rot_cw.template block<1, 3>(0, 0).eval();
+        const auto s_cw = std::sqrt(row0.dot(row0));
+        const auto rot_cw = (s_rot_cw / s_cw).eval();
+        const auto trans_cw = (Sim3_cw.template block<3, 1>(0, 3) / s_cw).eval();
+        const auto cam_center = (-rot_cw.transpose() * trans_cw).eval();
+
+        frame_arrays fa;
+        flatten_frame(*keyfrm, fa);
+        // the level gate of this matcher reads keypts_ (projection.cc:387), the window undist_keypts_
+        for (size_t i = 0; i < fa.undist_keypts.size(); ++i) {
+            fa.undist_keypts[i].octave = keyfrm->keypts_.at(i).octave;
+        }
+        query_arrays qa;
+        qa.reserve(landmarks.size());
+        std::vector<Landmark*> query_lms;
+        std::vector<const Landmark*> already_matched; // std::set of the non-null entries, projection.cc:326-327
+        for (auto* m : matched_lms_in_keyfrm) {
+            if (m) {
+                already_matched.push_back(m);
+            }
+        }
+        std::sort(already_matched.begin(), already_matched.end());
+        for (auto* lm : landmarks) {
+            if (lm->will_be_erased()) {
+                continue;
+            }
+            if (std::binary_search(already_matched.begin(), already_matched.end(), static_cast<const Landmark*>(lm))) {
+                continue;
+            }
+            const auto pos_w = lm->get_pos_in_world();
+            typename std::remove_cv<typename std::remove_reference<decltype(lm->reproj_in_tracking_)>::type>::type reproj; // Vec2_t
+            float x_right;
+            if (!keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) {
+                continue;
+            }
+            const auto cam_to_lm_vec = (pos_w - cam_center).eval();
+            const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+            if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) {
+                continue;
+            }
+            if (cam_to_lm_vec.dot(lm->get_obs_mean_normal()) < 0.5 * cam_to_lm_dist) {
+                continue;
+            }
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, keyfrm);
+            const auto desc = lm->get_descriptor();
+            qa.push(reproj(0), reproj(1), x_right, static_cast<int>(pred_scale_level), 0.0f, desc, true, true);
+            query_lms.push_back(lm);
+        }
+        std::vector<uint8_t> occ(matched_lms_in_keyfrm.size(), 0);
+        for (size_t i = 0; i < occ.size(); ++i) {
+            occ[i] = matched_lms_in_keyfrm[i] ? 1 : 0;
+        }
+        std::vector<int32_t> matched(occ.size(), -1);
+        uint32_t num = 0;
+        check(ovs_match_by_sim3_transform(&fa.view, qa.finish(), occ.data(), margin, matched.data(), &num, device_));
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                matched_lms_in_keyfrm.at(i) = query_lms.at(matched[i]);
+            }
+        }
+        return num;
+    }
 };
 
 class robust final : public base {
@@ -459,6 +585,35 @@ public:
         for (size_t i = 0; i < matched.size(); ++i) {
             if (matched[i] >= 0) {
                 matched_lms_in_frm[i] = keyfrm_lms.at(matched[i]);
+            }
+        }
+        return num;
+    }
+
+    // bow_tree.cc:124-246
+    template <class Keyframe, class Landmark>
+    unsigned int match_keyframes(Keyframe* keyfrm_1, Keyframe* keyfrm_2, std::vector<Landmark*>& matched_lms_in_keyfrm_1) const {
+        frame_arrays f1, f2;
+        flatten_frame(*keyfrm_1, f1);
+        flatten_frame(*keyfrm_2, f2);
+        std::vector<float> a1(f1.undist_keypts.size()), a2(f2.undist_keypts.size());
+        for (size_t i = 0; i < a1.size(); ++i) a1[i] = f1.undist_keypts[i].angle;
+        for (size_t i = 0; i < a2.size(); ++i) a2[i] = f2.undist_keypts[i].angle;
+        const auto lms_1 = keyfrm_1->get_landmarks();
+        const auto lms_2 = keyfrm_2->get_landmarks();
+        std::vector<uint8_t> v1(lms_1.size(), 0), v2(lms_2.size(), 0);
+        for (size_t i = 0; i < v1.size(); ++i) v1[i] = (lms_1[i] && !lms_1[i]->will_be_erased()) ? 1 : 0;
+        for (size_t i = 0; i < v2.size(); ++i) v2[i] = (lms_2[i] && !lms_2[i]->will_be_erased()) ? 1 : 0;
+        const bow_arrays b1(keyfrm_1->bow_feat_vec_), b2(keyfrm_2->bow_feat_vec_);
+        std::vector<int32_t> matched(a1.size(), -1);
+        uint32_t num = 0;
+        check(ovs_bow_match_keyframes(&b1.v, f1.descriptors.data(), a1.data(), v1.data(), static_cast<int>(a1.size()),
+                                      &b2.v, f2.descriptors.data(), a2.data(), v2.data(), static_cast<int>(a2.size()),
+                                      lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num, device_));
+        matched_lms_in_keyfrm_1 = std::vector<Landmark*>(a1.size(), nullptr);
+        for (size_t i = 0; i < matched.size(); ++i) {
+            if (matched[i] >= 0) {
+                matched_lms_in_keyfrm_1[i] = lms_2.at(matched[i]);
             }
         }
         return num;

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <set>
 
 namespace mock {
 
@@ -26,6 +27,10 @@ struct vec3 {
     vec3 eval() const { return *this; }
     vec3 operator-() const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = -v[i]; return r; }
     vec3 operator+(const vec3& o) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] + o.v[i]; return r; }
+    vec3 operator-(const vec3& o) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] - o.v[i]; return r; }
+    vec3 operator/(double s) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = v[i] / s; return r; }
+    double dot(const vec3& o) const { return v[0] * o.v[0] + v[1] * o.v[1] + v[2] * o.v[2]; }
+    double norm() const { return std::sqrt(dot(*this)); }
 };
 struct mat33 {
     double m[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
@@ -33,6 +38,8 @@ struct mat33 {
     mat33 transpose() const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[j][i]; return r; }
     mat33 operator-() const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = -m[i][j]; return r; }
     vec3 operator*(const vec3& x) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2]; return r; }
+    mat33 operator/(double s) const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j] / s; return r; }
+    template <int R, int C> vec3 block(int r0, int) const { vec3 r; for (int j = 0; j < 3; ++j) r.v[j] = m[r0][j]; return r; } // block<1, 3>
 };
 template <int R, int C> struct block_type;
 template <> struct block_type<3, 3> { typedef mat33 type; };
@@ -86,6 +93,11 @@ struct landmark {
     int scale_level_in_tracking_ = 0;
     bool observed = true;
     vec3 get_pos_in_world() const { return pos; }
+    float get_min_valid_distance() const { return 0.1f; }
+    float get_max_valid_distance() const { return 1.0e9f; } // the toy camera has fx = 1: points sit hundreds of units off axis
+    vec3 get_obs_mean_normal() const { return pos / pos.norm(); }
+    int level = 0;
+    template <class F> unsigned int predict_scale_level(double, const F*) const { return static_cast<unsigned int>(level); }
     mat_u8 get_descriptor() const { return desc; }
     bool has_observation() const { return observed; }
     bool will_be_erased() const { return false; }
@@ -165,6 +177,7 @@ int main(int argc, char** argv) {
         lms.back()->pos.v[0] = frm[0].keypts_[i].x - dx; lms.back()->pos.v[1] = frm[0].keypts_[i].y; lms.back()->pos.v[2] = 1.0;
         lms.back()->desc.create(1, 32);
         std::memcpy(lms.back()->desc.data, frm[0].descriptors_.data + 32 * static_cast<size_t>(i), 32);
+        lms.back()->level = frm[0].keypts_[i].octave;
         frm[0].landmarks_[i] = lms.back().get();
     }
     const unsigned n_proj = match::projection(0.9f, true).match_current_and_last_frames(frm[1], frm[0], 15.0f);
@@ -172,7 +185,20 @@ int main(int argc, char** argv) {
     for (auto* lm : frm[1].landmarks_) written += lm != nullptr;
     std::vector<std::pair<int, int>> pairs;
     const unsigned n_bf = match::robust(0.75f, true).brute_force_match(frm[1], &frm[0], pairs);
-    std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu\n", frm[0].num_keypts_, frm[1].num_keypts_, n_proj,
-                written, n_bf, pairs.size());
-    return (n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100) ? 0 : 2;
+    // relocalisation-style projection of the keyframe's landmarks, Sim3 variant with the identity,
+    // BoW matching with every keypoint under one vocabulary node
+    frm[1].landmarks_.assign(frm[1].num_keypts_, nullptr);
+    const unsigned n_kf = match::projection(0.9f, true).match_frame_and_keyframe(frm[1], &frm[0], std::set<mock::landmark*>{}, 15.0f, 100);
+    std::vector<mock::landmark*> all_lms, sim3_matched(frm[1].num_keypts_, nullptr);
+    for (auto& lm : lms) all_lms.push_back(lm.get());
+    const unsigned n_sim3 = match::projection(0.9f, true).match_by_Sim3_transform(&frm[1], mock::mat44{}, all_lms, sim3_matched, 10.0f);
+    for (int f = 0; f < 2; ++f) {
+        for (unsigned i = 0; i < frm[f].num_keypts_; ++i) frm[f].bow_feat_vec_[7].push_back(i);
+    }
+    std::vector<mock::landmark*> bow_matched;
+    for (unsigned i = 0; i < frm[1].num_keypts_; ++i) frm[1].landmarks_[i] = all_lms[i % all_lms.size()];
+    const unsigned n_bow = match::bow_tree(0.75f, true).match_keyframes(&frm[0], &frm[1], bow_matched);
+    std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u\n",
+                frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow);
+    return (n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100) ? 0 : 2;
 }
