@@ -113,11 +113,16 @@ __device__ __forceinline__ const uint8_t* level_ptr(const plan_dev& p, const ima
 // coefficient pairs) are built on the host exactly as OpenCV builds xofs / ialpha / yofs / ibeta.
 // One thread produces four horizontally adjacent pixels and stores them as one dword.
 // -------------------------------------------------------------------------------------------------
+// Four bytes from an arbitrarily aligned address using aligned dword loads only: the dword at the
+// address rounded down to 4 and, when the address is not aligned, the next one (which then holds
+// at least the last requested byte, so it is backed by memory whenever the four bytes are).
 __device__ __forceinline__ u32 load_u32_unaligned(const uint8_t* p) {
-    // the compiler may lower this to one dword load: gfx950 global memory accepts unaligned dwords
-    u32 v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const u32* q = reinterpret_cast<const u32*>(a & ~static_cast<uintptr_t>(3));
+    const u32 sh = (u32)(a & 3);
+    const u32 x0 = q[0];
+    const u32 x1 = sh ? q[1] : 0u;
+    return __builtin_amdgcn_alignbyte(x1, x0, sh);
 }
 
 // 8 bytes from an arbitrarily aligned address using aligned dword loads only (reads the 12 bytes
