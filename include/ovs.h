@@ -400,6 +400,23 @@ int ovs_knn2_merge_dev(const ovs_knn2* d_lists, int n_lists, int nq, ovs_knn2* d
 /* Batched extract + match on resident frames (offline sequences)                             */
 /* ------------------------------------------------------------------------------------------ */
 
+/* ------------------------------------------------------------------------------------------ */
+/* match::area (monocular initializer)                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* area::match_in_consistent_area (src/openvslam/match/area.cc:8-112).
+ *   undist_keypts_1 / descs_1   frm_1.undist_keypts_ and descriptors_ (only octave-0 keypoints search)
+ *   frm_2                       the frame searched; its grid is queried with (margin, level 0..0)
+ *   prev_matched_pts            n1 x 2 floats, in/out: search centres, updated for matched keypoints
+ *   matched_indices_2_in_frm_1  out, n1 ints (-1 = none);  *num_matches = the return value
+ * The window queries and all Hamming distances run on the device; the overwrite rule of
+ * area.cc:46-49,75-85 (a later keypoint takes over a candidate it is strictly closer to) is a
+ * sequential pass over those distances on the host. */
+int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
+                                 const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
+                                 float lowe_ratio, int check_orientation,
+                                 int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches, int device);
+
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points
  * keep their scratch memory per (host thread, device, stream), so independent batches may be in

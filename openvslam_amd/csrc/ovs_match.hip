@@ -601,4 +601,144 @@ int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
     return OVS_OK;
 }
 
+int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
+                                 const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
+                                 float lowe_ratio, int check_orientation,
+                                 int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches, int device) {
+    if (n1 < 0 || !frm_2 || !num_matches || (n1 > 0 && (!undist_keypts_1 || !descs_1 || !prev_matched_pts || !matched_indices_2_in_frm_1))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    const int n2 = frm_2->num_keypts;
+    std::fill(matched_indices_2_in_frm_1, matched_indices_2_in_frm_1 + n1, -1);
+    *num_matches = 0;
+    // 1. windows of the octave-0 keypoints of frame 1 in frame 2 (device), reference order
+    std::vector<int> qidx;
+    std::vector<float> ref_xy, margins;
+    std::vector<int32_t> lv;
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 < undist_keypts_1[idx_1].octave) {
+            continue; // area.cc:24-26
+        }
+        qidx.push_back(idx_1);
+        ref_xy.push_back(prev_matched_pts[2 * idx_1]);
+        ref_xy.push_back(prev_matched_pts[2 * idx_1 + 1]);
+        margins.push_back(static_cast<float>(margin));
+        lv.push_back(undist_keypts_1[idx_1].octave); // min_level = max_level = scale_level_1, area.cc:29-30
+    }
+    const int nq = static_cast<int>(qidx.size());
+    if (nq == 0 || n2 == 0) {
+        return OVS_OK;
+    }
+    std::vector<uint32_t> offsets(static_cast<size_t>(nq) + 1), indices(static_cast<size_t>(nq) * 32 + 1024);
+    int rc = ovs_get_keypoints_in_cell(frm_2, nq, ref_xy.data(), margins.data(), lv.data(), lv.data(), indices.data(),
+                                       static_cast<int>(indices.size()), offsets.data(), device);
+    if (rc == OVS_ERR_CAPACITY) {
+        indices.resize(offsets[nq]);
+        rc = ovs_get_keypoints_in_cell(frm_2, nq, ref_xy.data(), margins.data(), lv.data(), lv.data(), indices.data(),
+                                       static_cast<int>(indices.size()), offsets.data(), device);
+    }
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    // 2. all (keypoint, candidate) distances on the device
+    const size_t np = offsets[nq];
+    std::vector<uint32_t> dist(np);
+    if (np) {
+        std::vector<uint8_t> a(np * 32), b(np * 32);
+        for (int q = 0; q < nq; ++q) {
+            for (uint32_t e = offsets[q]; e < offsets[q + 1]; ++e) {
+                std::memcpy(&a[32 * static_cast<size_t>(e)], descs_1 + 32 * static_cast<size_t>(qidx[q]), 32);
+                std::memcpy(&b[32 * static_cast<size_t>(e)], frm_2->descriptors + 32 * static_cast<size_t>(indices[e]), 32);
+            }
+        }
+        if (np > 0x7FFFFFFFu) {
+            return ovs::fail(OVS_ERR_UNSUPPORTED, "too many candidate pairs");
+        }
+        if ((rc = ovs_hamming_pairs(a.data(), b.data(), static_cast<int>(np), dist.data(), device)) != OVS_OK) {
+            return rc;
+        }
+    }
+    // 3. the reference's sequential pass (area.cc:19-92) over the precomputed distances
+    unsigned int num = 0;
+    std::vector<unsigned int> matched_dists_in_frm_2(n2, kMaxDist);
+    std::vector<int> matched_indices_1_in_frm_2(n2, -1);
+    std::vector<std::pair<float, int>> angle_entries;
+    for (int q = 0; q < nq; ++q) {
+        const int idx_1 = qidx[q];
+        unsigned int best_hamm_dist = kMaxDist, second_best_hamm_dist = kMaxDist;
+        int best_idx_2 = -1;
+        for (uint32_t e = offsets[q]; e < offsets[q + 1]; ++e) {
+            const uint32_t idx_2 = indices[e];
+            const unsigned int hamm_dist = dist[e];
+            if (matched_dists_in_frm_2[idx_2] <= hamm_dist) {
+                continue;
+            }
+            if (hamm_dist < best_hamm_dist) {
+                second_best_hamm_dist = best_hamm_dist;
+                best_hamm_dist = hamm_dist;
+                best_idx_2 = static_cast<int>(idx_2);
+            }
+            else if (hamm_dist < second_best_hamm_dist) {
+                second_best_hamm_dist = hamm_dist;
+            }
+        }
+        if (kThrLow < best_hamm_dist) {
+            continue;
+        }
+        if (second_best_hamm_dist * lowe_ratio < static_cast<float>(best_hamm_dist)) {
+            continue;
+        }
+        const int prev_idx_1 = matched_indices_1_in_frm_2[best_idx_2];
+        if (0 <= prev_idx_1) {
+            matched_indices_2_in_frm_1[prev_idx_1] = -1;
+            --num;
+        }
+        matched_indices_2_in_frm_1[idx_1] = best_idx_2;
+        matched_indices_1_in_frm_2[best_idx_2] = idx_1;
+        matched_dists_in_frm_2[best_idx_2] = best_hamm_dist;
+        ++num;
+        if (check_orientation) {
+            angle_entries.emplace_back(undist_keypts_1[idx_1].angle - frm_2->undist_keypts[best_idx_2].angle, idx_1);
+        }
+    }
+    if (check_orientation) {
+        // match::angle_checker (angle_checker.h:72-134): 30 bins, the three fullest stay
+        unsigned hist[30] = {0};
+        std::vector<int> bins(angle_entries.size());
+        for (size_t i = 0; i < angle_entries.size(); ++i) {
+            float delta_angle = angle_entries[i].first;
+            if (delta_angle < 0.0) {
+                delta_angle += 360.0;
+            }
+            if (360.0 <= delta_angle) {
+                delta_angle -= 360.0;
+            }
+            const int bin = static_cast<int>(lrintf(delta_angle * (1.0f / 30)));
+            if (bin < 0 || 30 <= bin) {
+                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "rotation bin out of range");
+            }
+            bins[i] = bin;
+            ++hist[bin];
+        }
+        unsigned order[30];
+        ovs_sort::index_sort_by_size(hist, order, 30);
+        for (size_t i = 0; i < angle_entries.size(); ++i) {
+            const unsigned bin = static_cast<unsigned>(bins[i]);
+            if (bin != order[0] && bin != order[1] && bin != order[2] && 0 <= matched_indices_2_in_frm_1[angle_entries[i].second]) {
+                matched_indices_2_in_frm_1[angle_entries[i].second] = -1;
+                --num;
+            }
+        }
+    }
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 <= matched_indices_2_in_frm_1[idx_1]) {
+            const ovs_keypoint& kp = frm_2->undist_keypts[matched_indices_2_in_frm_1[idx_1]];
+            prev_matched_pts[2 * idx_1] = kp.x;
+            prev_matched_pts[2 * idx_1 + 1] = kp.y;
+        }
+    }
+    *num_matches = num;
+    return OVS_OK;
+}
+
 } // extern "C"

@@ -171,3 +171,22 @@ class stereo:
                                        A.ptr(self._dl, A.u8p), A.ptr(self._dr, A.u8p), A.ptr(self._sf, A.f32p), A.ptr(self._isf, A.f32p),
                                        self.focal_x_baseline_, self.true_baseline_, A.ptr(xr, A.f32p), A.ptr(depths, A.f32p), self.device))
         return xr, depths
+
+
+class area(base):
+    """match::area (src/openvslam/match/area.h): the matcher of the monocular initializer."""
+
+    def __init__(self, lowe_ratio=0.9, check_orientation=True, device=0):
+        super().__init__(lowe_ratio, check_orientation, device)
+
+    def match_in_consistent_area(self, undist_keypts_1, descs_1, frm_2_view, prev_matched_pts, margin):
+        """Returns (num_matches, matched_indices_2_in_frm_1); prev_matched_pts ([n1, 2] float32) is updated in place."""
+        k1 = np.ascontiguousarray(undist_keypts_1, dtype=A.KEYPOINT_DTYPE)
+        d1 = np.ascontiguousarray(descs_1, dtype=np.uint8).reshape(-1, 32)
+        assert prev_matched_pts.dtype == np.float32 and prev_matched_pts.flags["C_CONTIGUOUS"] and prev_matched_pts.shape == (len(k1), 2)
+        matched = np.full(len(k1), -1, dtype=np.int32)
+        num = C.c_uint32(0)
+        check(lib().ovs_match_in_consistent_area(A.ptr(k1, A.kpp), A.ptr(d1, A.u8p), len(k1), frm_2_view.ref(), A.ptr(prev_matched_pts, A.f32p),
+                                                 int(margin), self.lowe_ratio_, int(self.check_orientation_), A.ptr(matched, A.i32p),
+                                                 C.byref(num), self.device))
+        return num.value, matched

@@ -160,6 +160,12 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
                             const uint8_t* valid_2, int n2,
                             float lowe_ratio, int check_orientation,
                             int32_t* matched_idx2_in_kf1, uint32_t* num_matches);
+/* match::area::match_in_consistent_area (src/openvslam/match/area.cc:8-112) */
+int ovo_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
+                                 const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
+                                 float lowe_ratio, int check_orientation,
+                                 int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches);
+
 int ovo_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
                                 const ovs_keypoint* undist_keypts_1, const double* bearings_1,
                                 const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,

@@ -1412,3 +1412,91 @@ int ovo_match_batch_current_and_last(const ovs_keypoint* kps, const uint8_t* des
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// match::area::match_in_consistent_area (src/openvslam/match/area.cc:8-112): the matcher of the
+// monocular initializer.  frm_1 is given by its undistorted keypoints and descriptors, frm_2 as a
+// frame view; prev_matched_pts (n1 x 2, in/out) as in the reference.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ovo_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
+                                            const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
+                                            float lowe_ratio_, int check_orientation,
+                                            int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches_out) {
+    unsigned int num_matches = 0;
+    ovo::angle_checker angle_checker;
+    const auto cells = ovo::assign_keypoints_to_grid(*frm_2);
+    const unsigned int n2 = frm_2->num_keypts;
+    for (int i = 0; i < n1; ++i) {
+        matched_indices_2_in_frm_1[i] = -1;
+    }
+    std::vector<unsigned int> matched_dists_in_frm_2(n2, MAX_HAMMING_DIST);
+    std::vector<int> matched_indices_1_in_frm_2(n2, -1);
+
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        const auto& undist_keypt_1 = undist_keypts_1[idx_1];
+        const auto scale_level_1 = undist_keypt_1.octave;
+        if (0 < scale_level_1) {
+            continue;
+        }
+        const auto indices = ovo::get_keypoints_in_cell(*frm_2, cells, prev_matched_pts[2 * idx_1], prev_matched_pts[2 * idx_1 + 1],
+                                                        static_cast<float>(margin), scale_level_1, scale_level_1);
+        if (indices.empty()) {
+            continue;
+        }
+        const uint8_t* desc_1 = descs_1 + 32 * static_cast<size_t>(idx_1);
+        unsigned int best_hamm_dist = MAX_HAMMING_DIST;
+        unsigned int second_best_hamm_dist = MAX_HAMMING_DIST;
+        int best_idx_2 = -1;
+        for (const auto idx_2 : indices) {
+            const auto hamm_dist = ovo::hamming_32(desc_1, frm_2->descriptors + 32 * static_cast<size_t>(idx_2));
+            if (matched_dists_in_frm_2.at(idx_2) <= hamm_dist) {
+                continue;
+            }
+            if (hamm_dist < best_hamm_dist) {
+                second_best_hamm_dist = best_hamm_dist;
+                best_hamm_dist = hamm_dist;
+                best_idx_2 = idx_2;
+            }
+            else if (hamm_dist < second_best_hamm_dist) {
+                second_best_hamm_dist = hamm_dist;
+            }
+        }
+        if (HAMMING_DIST_THR_LOW < best_hamm_dist) {
+            continue;
+        }
+        if (second_best_hamm_dist * lowe_ratio_ < static_cast<float>(best_hamm_dist)) {
+            continue;
+        }
+        const auto prev_idx_1 = matched_indices_1_in_frm_2.at(best_idx_2);
+        if (0 <= prev_idx_1) {
+            matched_indices_2_in_frm_1[prev_idx_1] = -1;
+            --num_matches;
+        }
+        matched_indices_2_in_frm_1[idx_1] = best_idx_2;
+        matched_indices_1_in_frm_2.at(best_idx_2) = idx_1;
+        matched_dists_in_frm_2.at(best_idx_2) = best_hamm_dist;
+        ++num_matches;
+        if (check_orientation) {
+            const auto delta_angle = undist_keypts_1[idx_1].angle - frm_2->undist_keypts[best_idx_2].angle;
+            angle_checker.append_delta_angle(delta_angle, idx_1);
+        }
+    }
+    if (check_orientation) {
+        const auto invalid_matches = angle_checker.get_invalid_matches();
+        for (const auto invalid_idx_1 : invalid_matches) {
+            if (0 <= matched_indices_2_in_frm_1[invalid_idx_1]) {
+                matched_indices_2_in_frm_1[invalid_idx_1] = -1;
+                --num_matches;
+            }
+        }
+    }
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 <= matched_indices_2_in_frm_1[idx_1]) {
+            const auto& pt = frm_2->undist_keypts[matched_indices_2_in_frm_1[idx_1]];
+            prev_matched_pts[2 * idx_1] = pt.x;
+            prev_matched_pts[2 * idx_1 + 1] = pt.y;
+        }
+    }
+    *num_matches_out = num_matches;
+    return 0;
+}

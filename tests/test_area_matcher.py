@@ -1,0 +1,75 @@
+"""match::area::match_in_consistent_area (src/openvslam/match/area.cc:8-112): first-principles
+checks of the oracle on the CPU, GPU parity against it on extracted frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from openvslam_amd import _abi as A
+
+SF = np.array([1.2 ** i for i in range(8)], dtype=np.float32)
+
+
+def oracle_area(k1, d1, view2, prev, margin, lowe, check):
+    prev = prev.copy()
+    m = np.full(len(k1), -7, np.int32)
+    num = C.c_uint32(0)
+    oracle.check(oracle.lib().ovo_match_in_consistent_area(A.ptr(k1, A.kpp), A.ptr(d1, A.u8p), len(k1), view2.ref(), A.ptr(prev, A.f32p),
+                                                           margin, np.float32(lowe), check, A.ptr(m, A.i32p), C.byref(num)))
+    return num.value, m, prev
+
+
+def test_identity_and_level_gate():
+    """A frame matched with itself around its own keypoints: every octave-0 keypoint matches itself,
+    higher octaves never search (area.cc:24-26), the search centres move onto the matches."""
+    rng = np.random.default_rng(3)
+    n = 300
+    k = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k["x"], k["y"] = rng.uniform(10, 630, n), rng.uniform(10, 470, n)
+    k["octave"] = rng.integers(0, 3, n)
+    k["angle"] = rng.uniform(0, 360, n)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    view = A.make_frame_view(k, d, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.stack([k["x"], k["y"]], axis=1).astype(np.float32) + np.float32(1.5)
+    num, m, new_prev = oracle_area(k, d, view, prev, 30, 0.9, 1)
+    lvl0 = k["octave"] == 0
+    assert np.array_equal(m[lvl0], np.nonzero(lvl0)[0]) and np.all(m[~lvl0] == -1)
+    assert num == int(lvl0.sum())
+    assert np.array_equal(new_prev[lvl0, 0], k["x"][lvl0]) and np.array_equal(new_prev[~lvl0], prev[~lvl0])
+
+
+def test_closer_keypoint_takes_over():
+    """area.cc:46-49,75-85: a later keypoint that is strictly closer to a candidate replaces the
+    earlier match; an equally distant one does not."""
+    k1 = np.zeros(3, dtype=A.KEYPOINT_DTYPE)
+    k1["x"], k1["y"] = 100.0, 100.0
+    k2 = np.zeros(1, dtype=A.KEYPOINT_DTYPE)
+    k2["x"], k2["y"] = 101.0, 100.0
+    d2 = np.zeros((1, 32), np.uint8)
+    d1 = np.zeros((3, 32), np.uint8)
+    d1[0, 0] = 0x0F   # distance 4
+    d1[1, 0] = 0x03   # distance 2: takes over
+    d1[2, 0] = 0x30   # distance 2: not strictly closer
+    view = A.make_frame_view(k2, d2, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.full((3, 2), 100.0, np.float32)
+    num, m, _ = oracle_area(k1, d1, view, prev, 10, 0.9, 0)
+    assert num == 1 and m.tolist() == [-1, 0, -1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("check,lowe,margin", [(1, 0.9, 100), (0, 0.75, 30), (1, 1.0, 300)])
+def test_gpu_matches_oracle_on_a_sequence(check, lowe, margin):
+    from openvslam_amd import match, synth
+    frames = synth.make_sequence(640, 480, 2, seed=12, dx=5, dy=2)
+    ext = oracle.OrbExtractor(max_num_keypts=1500)
+    k1, d1 = ext.extract(frames[0])
+    k2, d2 = ext.extract(frames[1])
+    view2 = A.make_frame_view(k2, d2, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32))
+    want_num, want_m, want_prev = oracle_area(k1, d1, view2, prev, margin, lowe, check)
+    got_prev = prev.copy()
+    got_num, got_m = match.area(lowe, bool(check)).match_in_consistent_area(k1, d1, view2, got_prev, margin)
+    assert got_num == want_num and np.array_equal(got_m, want_m)
+    assert got_prev.tobytes() == want_prev.tobytes()
+    assert got_num > 50
