@@ -417,6 +417,21 @@ int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint
                                  float lowe_ratio, int check_orientation,
                                  int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches, int device);
 
+/* ------------------------------------------------------------------------------------------ */
+/* data::landmark::compute_descriptor                                                         */
+/* ------------------------------------------------------------------------------------------ */
+
+/* landmark::compute_descriptor (src/openvslam/data/landmark.cc:127-184) for a batch of landmarks
+ * (every new / merged landmark of a mapping step).  Landmark l observes the descriptors
+ * descs[offsets[l] .. offsets[l+1]) (those of keyframes that are not being erased, in the
+ * iteration order of its observation map); best_idx[l] is the index inside that range of the
+ * descriptor with the smallest median Hamming distance to all of the landmark's descriptors
+ * (median = element floor(0.5 * (n - 1)) of the sorted row, self distance included), the first
+ * one on ties, or -1 for a landmark without observations.  Host buffers; at most 4096
+ * observations per landmark. */
+int ovs_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks,
+                                     int32_t* best_idx, int device);
+
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points
  * keep their scratch memory per (host thread, device, stream), so independent batches may be in

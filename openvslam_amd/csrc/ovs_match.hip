@@ -193,6 +193,80 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const ovs_knn2* __restrict__
 }
 
 
+// landmark::compute_descriptor: one wavefront per landmark.  For every row r of the landmark's
+// distance matrix the lanes split the columns, build the histogram of the 257 possible distances
+// in LDS and find the bin holding element k = floor(0.5 * (n - 1)) of the sorted row; lane 0 keeps
+// the first row with the smallest median.
+__global__ __launch_bounds__(64) void k_landmark_median(const uint8_t* __restrict__ descs, const u32* __restrict__ offsets, int n_landmarks,
+                                                        int* __restrict__ best_idx) {
+    __shared__ u32 hist[264];
+    const int l = blockIdx.x, lane = threadIdx.x;
+    const u32 first = offsets[l], n = offsets[l + 1] - first;
+    if (n == 0) {
+        if (lane == 0) {
+            best_idx[l] = -1;
+        }
+        return;
+    }
+    const uint8_t* base = descs + 32 * (size_t)first;
+    const u32 k = (u32)(0.5 * (double)(n - 1));
+    u32 best_median = kMaxDist, best = 0;
+    for (u32 r = 0; r < n; ++r) {
+        for (int b = lane; b < 264; b += 64) {
+            hist[b] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u32 dr[8];
+        load_desc(base + 32 * (size_t)r, dr);
+        for (u32 j = lane; j < n; j += 64) {
+            u32 dj[8];
+            load_desc(base + 32 * (size_t)j, dj);
+            atomicAdd(&hist[hamming8(dr, dj)], 1u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lane b owns bins 5b .. 5b+4 (320 >= 257): inclusive prefix over lanes, then inside the lane
+        u32 own[5], sum = 0;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int bin = 5 * lane + t;
+            own[t] = bin < 264 ? hist[bin] : 0u;
+            sum += own[t];
+        }
+        u32 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = __shfl_up(inc, d);
+            if (lane >= d) {
+                inc += t;
+            }
+        }
+        u32 run = inc - sum; // elements in lower bins
+        u32 median = 0xFFFFFFFFu;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (median == 0xFFFFFFFFu && run <= k && k < run + own[t]) {
+                median = (u32)(5 * lane + t);
+            }
+            run += own[t];
+        }
+        // exactly one lane found it
+        const u64 who = __ballot(median != 0xFFFFFFFFu);
+        median = __shfl(median, __ffsll((long long)who) - 1);
+        if (median < best_median) {
+            best_median = median;
+            best = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {
+        best_idx[l] = (int)best;
+    }
+}
+
+
 } // namespace
 
 struct ovs_desc_db {
@@ -738,6 +812,50 @@ int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint
         }
     }
     *num_matches = num;
+    return OVS_OK;
+}
+
+int ovs_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks,
+                                     int32_t* best_idx, int device) {
+    if (n_landmarks < 0 || (n_landmarks > 0 && (!offsets || !best_idx))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if (n_landmarks == 0) {
+        return OVS_OK;
+    }
+    const size_t total = offsets[n_landmarks];
+    for (int l = 0; l < n_landmarks; ++l) {
+        if (offsets[l + 1] < offsets[l]) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+        }
+        if (offsets[l + 1] - offsets[l] > 4096) {
+            return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 4096 observations per landmark are not supported");
+        }
+    }
+    if (total > 0 && !descs) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) return rc;
+    const size_t nl = n_landmarks;
+    if ((rc = ctx->arena.reserve(al(std::max<size_t>(total, 1) * 32) + al((nl + 1) * 4) + al(nl * 4))) != OVS_OK) return rc;
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    auto* d_desc = cv.take<uint8_t>(std::max<size_t>(total, 1) * 32);
+    auto* d_off = cv.take<u32>(nl + 1);
+    auto* d_best = cv.take<int>(nl);
+    if (total) {
+        OVS_HIP(hipMemcpyAsync(d_desc, descs, total * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    OVS_HIP(hipMemcpyAsync(d_off, offsets, (nl + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    OVS_LAUNCH("k_landmark_median", k_landmark_median, dim3(n_landmarks), dim3(64), 0, ctx->stream, d_desc, d_off, n_landmarks, d_best);
+    OVS_HIP(hipMemcpyAsync(best_idx, d_best, nl * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OVS_HIP(hipStreamSynchronize(ctx->stream));
     return OVS_OK;
 }
 

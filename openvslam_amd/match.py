@@ -190,3 +190,14 @@ class area(base):
                                                  int(margin), self.lowe_ratio_, int(self.check_orientation_), A.ptr(matched, A.i32p),
                                                  C.byref(num), self.device))
         return num.value, matched
+
+
+def landmark_compute_descriptors(descs, offsets, device=0):
+    """data::landmark::compute_descriptor for a batch of landmarks: landmark l observes
+    descs[offsets[l]:offsets[l+1]]; returns the index (inside its range) of its representative
+    descriptor, -1 where a landmark has no observation."""
+    d = np.ascontiguousarray(descs, dtype=np.uint8).reshape(-1, 32)
+    off = np.ascontiguousarray(offsets, dtype=np.uint32)
+    best = np.full(len(off) - 1, -9, dtype=np.int32)
+    check(lib().ovs_landmark_compute_descriptors(A.ptr(d, A.u8p), A.ptr(off, A.u32p), len(off) - 1, A.ptr(best, A.i32p), device))
+    return best

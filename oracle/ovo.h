@@ -160,6 +160,9 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
                             const uint8_t* valid_2, int n2,
                             float lowe_ratio, int check_orientation,
                             int32_t* matched_idx2_in_kf1, uint32_t* num_matches);
+/* data::landmark::compute_descriptor (src/openvslam/data/landmark.cc:127-184), batched */
+int ovo_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks, int32_t* best_idx);
+
 /* match::area::match_in_consistent_area (src/openvslam/match/area.cc:8-112) */
 int ovo_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
                                  const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,

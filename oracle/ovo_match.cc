@@ -1500,3 +1500,42 @@ extern "C" int ovo_match_in_consistent_area(const ovs_keypoint* undist_keypts_1,
     *num_matches_out = num_matches;
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// data::landmark::compute_descriptor (src/openvslam/data/landmark.cc:127-184) for a batch of
+// landmarks: landmark l observes descriptors descs[offsets[l] .. offsets[l+1]); best_idx[l] is the
+// index (inside its own range) of the descriptor whose median distance to the others is smallest,
+// first one on ties; -1 for a landmark without observations (the reference returns early).
+// ---------------------------------------------------------------------------------------------
+extern "C" int ovo_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks, int32_t* best_idx_out) {
+    for (int l = 0; l < n_landmarks; ++l) {
+        const unsigned int num_descs = offsets[l + 1] - offsets[l];
+        if (num_descs == 0) {
+            best_idx_out[l] = -1;
+            continue;
+        }
+        const uint8_t* base = descs + 32 * static_cast<size_t>(offsets[l]);
+        std::vector<std::vector<unsigned int>> hamm_dists(num_descs, std::vector<unsigned int>(num_descs));
+        for (unsigned int i = 0; i < num_descs; ++i) {
+            hamm_dists.at(i).at(i) = 0;
+            for (unsigned int j = i + 1; j < num_descs; ++j) {
+                const auto dist = ovo::hamming_32(base + 32 * static_cast<size_t>(i), base + 32 * static_cast<size_t>(j));
+                hamm_dists.at(i).at(j) = dist;
+                hamm_dists.at(j).at(i) = dist;
+            }
+        }
+        unsigned int best_median_dist = MAX_HAMMING_DIST;
+        unsigned int best_idx = 0;
+        for (unsigned idx = 0; idx < num_descs; ++idx) {
+            std::vector<unsigned int> partial_hamm_dists(hamm_dists.at(idx).begin(), hamm_dists.at(idx).begin() + num_descs);
+            std::sort(partial_hamm_dists.begin(), partial_hamm_dists.end());
+            const auto median_dist = partial_hamm_dists.at(static_cast<unsigned int>(0.5 * (num_descs - 1)));
+            if (median_dist < best_median_dist) {
+                best_median_dist = median_dist;
+                best_idx = idx;
+            }
+        }
+        best_idx_out[l] = static_cast<int32_t>(best_idx);
+    }
+    return 0;
+}
