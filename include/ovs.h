@@ -401,6 +401,28 @@ int ovs_knn2_merge_dev(const ovs_knn2* d_lists, int n_lists, int nq, ovs_knn2* d
 /* ------------------------------------------------------------------------------------------ */
 
 /* ------------------------------------------------------------------------------------------ */
+/* match::fuse                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The candidate search of fuse::detect_duplication (src/openvslam/match/fuse.cc:67-102,
+ * replace_mode = 0) and fuse::replace_duplication (fuse.cc:173-236, replace_mode = 1): for every
+ * landmark that passed the caller's visibility gates (`valid`), the keypoint of the keyframe with
+ * the smallest Hamming distance (<= HAMMING_DIST_THR_LOW, first one on ties) inside the window
+ * margin * scale_factors[pred level], or -1.  Queries do not exclude each other; what happens to a
+ * hit (add the observation, or merge with the landmark already there) is landmark bookkeeping and
+ * stays with the caller, in query order.
+ *   detect:  level gate `octave < pred - 1 || pred < octave` on SIGNED ints (fuse.cc:68,83-88); put
+ *            keypts_[i].octave into the view's keypoints, as the reference reads keypts_ here
+ *   replace: the same gate on UNSIGNED values (fuse.cc:191-196) plus the chi-square gate on the
+ *            reprojection error (5.99146 for two, 7.81473 for three degrees of freedom when the
+ *            keypoint has a stereo x_right >= 0, fuse.cc:198-222); reproj_xy_d holds the
+ *            double-precision reprojection the reference computes (n x 2), q->x_right its x_right,
+ *            inv_level_sigma_sq the keyframe's table (num_scale_levels floats) */
+int ovs_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
+                             const float* inv_level_sigma_sq, float margin, int replace_mode,
+                             int32_t* best_idx_of_query, int device);
+
+/* ------------------------------------------------------------------------------------------ */
 /* match::area (monocular initializer)                                                        */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -99,6 +99,7 @@ def _declare(L):
                                               A.f64p, A.f64p, A.f32p, i, i, A.u32p, A.u32p, i]
     L.ovs_match_in_consistent_area.argtypes = [A.kpp, A.u8p, i, fv, A.f32p, i, C.c_float, i, A.i32p, A.u32p, i]
     L.ovs_landmark_compute_descriptors.argtypes = [A.u8p, A.u32p, i, A.i32p, i]
+    L.ovs_fuse_best_candidates.argtypes = [fv, pq, A.f64p, A.f32p, C.c_float, i, A.i32p, i]
     L.ovs_desc_db_create.argtypes = [i, C.POINTER(vp)]
     L.ovs_desc_db_destroy.argtypes = [vp]
     L.ovs_desc_db_destroy.restype = None

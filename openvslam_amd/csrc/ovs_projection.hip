@@ -36,9 +36,13 @@ enum proj_kind {
     kFrameKeyfrm = 2, // projection::match_frame_and_keyframe
     kSim3 = 3,        // projection::match_by_Sim3_transform
     kOneWay = 4,      // one direction of projection::match_keyframes_mutually
-    kRange = 5        // robust::brute_force_match / bow_tree::match_*: every query names one contiguous
+    kRange = 5,       // robust::brute_force_match / bow_tree::match_*: every query names one contiguous
                       // range of the candidate list; best <= 50 and Lowe's ratio against the runner-up
+    kFuseDetect = 6,  // fuse::detect_duplication: per query best keypoint, signed level gate, <= 50
+    kFuseReplace = 7  // fuse::replace_duplication: unsigned level gate + chi-square reprojection gate
 };
+
+__host__ __device__ inline bool kind_is_one_way(int kind) { return kind == kOneWay || kind == kFuseDetect || kind == kFuseReplace; }
 
 struct frame_dev {
     int n;
@@ -51,6 +55,7 @@ struct frame_dev {
     const u32* cell_start; // num_cols * num_rows + 1
     const uint4* g_entry;  // grid order: {x bits, y bits, octave, keypoint index}
     const uint4* g_desc;   // grid order: two uint4 per keypoint
+    const float* inv_level_sigma_sq; // kFuseReplace only
 };
 
 struct query_dev {
@@ -64,6 +69,7 @@ struct query_dev {
     const uint8_t* has_obs;
     const u32* range_lo; // kRange: candidates of query i are entries [range_lo[i], range_hi[i])
     const u32* range_hi;
+    const double* reproj_xy_d; // kFuseReplace: the double-precision reprojection of the chi-square gate
 };
 
 struct proj_params {
@@ -238,11 +244,15 @@ struct query_ctx {
     bool stereo_gate;
     bool ranged; // kRange: no window, no geometric gates
     u32 lo, hi;
+    int fuse;       // 0: none, 1: signed level gate (fuse.cc:86), 2: unsigned gate + chi-square gate (fuse.cc:194-222)
+    double rxd, ryd;
 };
 
 __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const frame_dev& f, const query_dev& q, int qi, query_ctx& c) {
     c.ranged = false;
     c.lo = c.hi = 0;
+    c.fuse = 0;
+    c.rxd = c.ryd = 0.0;
     if (pp.kind == kRange) {
         c.ranged = true;
         c.lo = q.range_lo[qi];
@@ -289,6 +299,21 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
         case kFrameKeyfrm:
             c.min_level = sl - 1;
             c.max_level = sl + 1;
+            break;
+        case kFuseDetect:
+            c.min_level = -1;
+            c.max_level = -1;
+            c.fuse = 1;
+            break;
+        case kFuseReplace:
+            c.min_level = -1;
+            c.max_level = -1;
+            c.ugate = true;
+            c.fuse = 2;
+            c.rxd = q.reproj_xy_d[2 * qi];
+            c.ryd = q.reproj_xy_d[2 * qi + 1];
+            c.rx = (float)c.rxd; // get_keypoints_in_cell takes floats: the doubles narrow at the call
+            c.ry = (float)c.ryd;
             break;
         default:
             c.min_level = -1;
@@ -353,6 +378,29 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
             if (c.margin < err) {
                 return false;
             }
+        }
+    }
+    if (c.fuse == 1) {
+        // int scale_level, int pred_scale_level (fuse.cc:68,83-88)
+        if (oct < (int)c.sl - 1 || (int)c.sl < oct) {
+            return false;
+        }
+    }
+    else if (c.fuse == 2) {
+        // fuse.cc:198-222: reproj is double, keypoint and x_right are float; products and sums in the
+        // reference's order without contraction
+        const double e_x = __dsub_rn(c.rxd, (double)__uint_as_float(en.x));
+        const double e_y = __dsub_rn(c.ryd, (double)__uint_as_float(en.y));
+        double err_sq = __dadd_rn(__dmul_rn(e_x, e_x), __dmul_rn(e_y, e_y));
+        const float sx = f.sxr ? f.sxr[idx] : -1.0f;
+        double chi = (double)5.99146f;
+        if (sx >= 0) {
+            const float e_r = __fsub_rn(c.xr, sx);
+            err_sq = __dadd_rn(err_sq, (double)__fmul_rn(e_r, e_r));
+            chi = (double)7.81473f;
+        }
+        if (chi < __dmul_rn(err_sq, (double)f.inv_level_sigma_sq[oct])) {
+            return false;
         }
     }
     return true;
@@ -520,6 +568,8 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
         case kFrameKeyfrm:
             return bd <= pp.thr;
         case kSim3:
+        case kFuseDetect:
+        case kFuseReplace:
             return bd <= kThrLow;
         default:
             return bd <= kThrHigh; // kCurrLast, kOneWay
@@ -567,9 +617,10 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     }
     __syncthreads();
 
-    const bool excl = pp.kind != kOneWay;
+    const bool excl = !kind_is_one_way(pp.kind);
     const int needed = (pp.kind == kFrameLms || pp.kind == kRange) ? 2 : 1;
-    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr : ((pp.kind == kSim3 || pp.kind == kRange) ? kThrLow : kThrHigh);
+    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr
+                                             : ((pp.kind == kSim3 || pp.kind == kRange || pp.kind == kFuseDetect || pp.kind == kFuseReplace) ? kThrLow : kThrHigh);
     u32 mynum = 0;
     for (int base = 0; base < nq; base += 64) {
         const int mq = base + lane;
@@ -889,6 +940,8 @@ __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restr
         P.q.has_obs = nullptr;
         P.q.range_lo = nullptr;
         P.q.range_hi = nullptr;
+        P.q.reproj_xy_d = nullptr;
+        P.frm.inv_level_sigma_sq = nullptr;
         P.occupied = nullptr;
         P.lists = lists + qo * kTopK;
         P.totals = totals + qo;
@@ -1007,7 +1060,8 @@ int upload_frame(const ovs_frame_view* f, carver& cv, hipStream_t st, frame_dev&
 
 // Runs one projection-matching problem given host views.
 int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const uint8_t* occupied, proj_params pp,
-                   int32_t* matched_out, int32_t* best_of_query_out, uint32_t* num_matches, int device) {
+                   int32_t* matched_out, int32_t* best_of_query_out, uint32_t* num_matches, int device,
+                   const double* reproj_xy_d = nullptr, const float* inv_level_sigma_sq = nullptr) {
     int rc = validate_frame(frm);
     if (rc != OVS_OK) {
         return rc;
@@ -1028,7 +1082,8 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     }
     const size_t n = frm->num_keypts, nq = q->n;
     const size_t total = frame_bytes(frm) + al(n) + al(nq * 8) + al(nq * 4) * 3 + al(nq * 32) + al(nq) * 2
-                         + al(nq * kTopK * 8) + al(nq * 4) * 2 + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem));
+                         + al(nq * kTopK * 8) + al(nq * 4) * 2 + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem))
+                         + al(nq * 16) + al(static_cast<size_t>(frm->num_scale_levels) * 4);
     if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
         return rc;
     }
@@ -1063,6 +1118,16 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     auto* d_num = cv.take<u32>(1);
     auto* d_err = cv.take<int>(1);
     auto* d_prob = cv.take<proj_problem>(1);
+    auto* d_rxy_d = cv.take<double>(nq * 2);
+    auto* d_isig = cv.take<float>(static_cast<size_t>(frm->num_scale_levels));
+    if (reproj_xy_d) {
+        OVS_HIP(up(d_rxy_d, reproj_xy_d, nq * 16));
+        P.q.reproj_xy_d = d_rxy_d;
+    }
+    if (inv_level_sigma_sq) {
+        OVS_HIP(up(d_isig, inv_level_sigma_sq, static_cast<size_t>(frm->num_scale_levels) * 4));
+        P.frm.inv_level_sigma_sq = d_isig;
+    }
 
     if (occupied) {
         OVS_HIP(up(d_occ, occupied, n));
@@ -1452,6 +1517,17 @@ int ovs_match_keyframe_one_way(const ovs_frame_view* keyfrm, const ovs_proj_quer
                                int32_t* best_idx_of_query, int device) {
     proj_params pp{kOneWay, margin, OVS_DIR_NONE, 0, 0.0f, kThrHigh, 0, 1, 0};
     return run_projection(keyfrm, q, nullptr, pp, nullptr, best_idx_of_query, nullptr, device);
+}
+
+int ovs_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
+                             const float* inv_level_sigma_sq, float margin, int replace_mode,
+                             int32_t* best_idx_of_query, int device) {
+    if (replace_mode && (!inv_level_sigma_sq || (q && q->n > 0 && (!reproj_xy_d || !q->x_right)))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "replace mode needs the double reprojections, x_right and inv_level_sigma_sq");
+    }
+    proj_params pp{replace_mode ? kFuseReplace : kFuseDetect, margin, OVS_DIR_NONE, 0, 0.0f, kThrLow, 0, 1, 0};
+    return run_projection(keyfrm, q, nullptr, pp, nullptr, best_idx_of_query, nullptr, device, replace_mode ? reproj_xy_d : nullptr,
+                          replace_mode ? inv_level_sigma_sq : nullptr);
 }
 
 int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, int n2,

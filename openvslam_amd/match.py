@@ -201,3 +201,21 @@ def landmark_compute_descriptors(descs, offsets, device=0):
     best = np.full(len(off) - 1, -9, dtype=np.int32)
     check(lib().ovs_landmark_compute_descriptors(A.ptr(d, A.u8p), A.ptr(off, A.u32p), len(off) - 1, A.ptr(best, A.i32p), device))
     return best
+
+
+class fuse:
+    """The device part of match::fuse (src/openvslam/match/fuse.cc): per landmark the best keypoint
+    of the keyframe; the caller applies add_observation / replace in query order."""
+
+    def __init__(self, device=0):
+        self.device = device
+
+    def best_candidates(self, keyfrm_view, queries, margin, reproj_xy_d=None, inv_level_sigma_sq=None):
+        """detect_duplication search when reproj_xy_d is None, replace_duplication search otherwise."""
+        n = queries.struct.n
+        best = np.full(n, -9, dtype=np.int32)
+        rd = None if reproj_xy_d is None else np.ascontiguousarray(reproj_xy_d, dtype=np.float64).reshape(n, 2)
+        isg = None if inv_level_sigma_sq is None else np.ascontiguousarray(inv_level_sigma_sq, dtype=np.float32)
+        check(lib().ovs_fuse_best_candidates(keyfrm_view.ref(), queries.ref(), A.ptr(rd, A.f64p), A.ptr(isg, A.f32p), margin,
+                                             0 if rd is None else 1, A.ptr(best, A.i32p), self.device))
+        return best

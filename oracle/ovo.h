@@ -160,6 +160,10 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
                             const uint8_t* valid_2, int n2,
                             float lowe_ratio, int check_orientation,
                             int32_t* matched_idx2_in_kf1, uint32_t* num_matches);
+/* candidate search of fuse::detect_duplication / replace_duplication (src/openvslam/match/fuse.cc) */
+int ovo_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
+                             const float* inv_level_sigma_sq, float margin, int replace_mode, int32_t* best_idx_of_query);
+
 /* data::landmark::compute_descriptor (src/openvslam/data/landmark.cc:127-184), batched */
 int ovo_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks, int32_t* best_idx);
 

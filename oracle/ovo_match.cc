@@ -1539,3 +1539,86 @@ extern "C" int ovo_landmark_compute_descriptors(const uint8_t* descs, const uint
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The candidate search of fuse::detect_duplication (src/openvslam/match/fuse.cc:67-102) and
+// fuse::replace_duplication (fuse.cc:173-236).  The visibility gates before it and the landmark
+// bookkeeping after it are the caller's; `valid` marks the landmarks that reach the search.
+// ---------------------------------------------------------------------------------------------
+extern "C" int ovo_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
+                                        const float* inv_level_sigma_sq, float margin, int replace_mode, int32_t* best_idx_of_query) {
+    const auto cells = ovo::assign_keypoints_to_grid(*keyfrm);
+    for (int i = 0; i < q->n; ++i) {
+        best_idx_of_query[i] = -1;
+        if (!q->valid[i]) {
+            continue;
+        }
+        if (q->scale_level[i] < 0 || keyfrm->num_scale_levels <= q->scale_level[i]) {
+            return ovo::fail(-5, "scale level out of range"); // scale_factors_.at(pred_scale_level)
+        }
+        const uint8_t* lm_desc = q->desc + 32 * static_cast<size_t>(i);
+        unsigned int best_dist = MAX_HAMMING_DIST;
+        int best_idx = -1;
+        if (!replace_mode) {
+            const int pred_scale_level = q->scale_level[i];
+            const auto indices = ovo::get_keypoints_in_cell(*keyfrm, cells, q->reproj_xy[2 * i], q->reproj_xy[2 * i + 1],
+                                                            margin * keyfrm->scale_factors[pred_scale_level]);
+            for (const auto idx : indices) {
+                const auto scale_level = keyfrm->undist_keypts[idx].octave; // keypts_.at(idx).octave, supplied through the view
+                if (scale_level < pred_scale_level - 1 || pred_scale_level < scale_level) {
+                    continue;
+                }
+                const auto hamm_dist = ovo::hamming_32(lm_desc, keyfrm->descriptors + 32 * static_cast<size_t>(idx));
+                if (hamm_dist < best_dist) {
+                    best_dist = hamm_dist;
+                    best_idx = idx;
+                }
+            }
+        }
+        else {
+            const unsigned int pred_scale_level = static_cast<unsigned int>(q->scale_level[i]);
+            const double reproj[2] = {reproj_xy_d[2 * i], reproj_xy_d[2 * i + 1]};
+            const float x_right = q->x_right[i];
+            // get_keypoints_in_cell takes floats: the double reprojection narrows at the call (fuse.cc:176)
+            const auto indices = ovo::get_keypoints_in_cell(*keyfrm, cells, static_cast<float>(reproj[0]), static_cast<float>(reproj[1]),
+                                                            margin * keyfrm->scale_factors[pred_scale_level]);
+            for (const auto idx : indices) {
+                const auto& keypt = keyfrm->undist_keypts[idx];
+                const auto scale_level = static_cast<unsigned int>(keypt.octave);
+                if (scale_level < pred_scale_level - 1 || pred_scale_level < scale_level) {
+                    continue;
+                }
+                const float sxr = keyfrm->stereo_x_right ? keyfrm->stereo_x_right[idx] : -1.0f;
+                if (sxr >= 0) {
+                    const auto e_x = reproj[0] - keypt.x;
+                    const auto e_y = reproj[1] - keypt.y;
+                    const auto e_x_right = x_right - sxr;
+                    const auto reproj_error_sq = e_x * e_x + e_y * e_y + e_x_right * e_x_right;
+                    constexpr float chi_sq_3D = 7.81473;
+                    if (chi_sq_3D < reproj_error_sq * inv_level_sigma_sq[scale_level]) {
+                        continue;
+                    }
+                }
+                else {
+                    const auto e_x = reproj[0] - keypt.x;
+                    const auto e_y = reproj[1] - keypt.y;
+                    const auto reproj_error_sq = e_x * e_x + e_y * e_y;
+                    constexpr float chi_sq_2D = 5.99146;
+                    if (chi_sq_2D < reproj_error_sq * inv_level_sigma_sq[scale_level]) {
+                        continue;
+                    }
+                }
+                const auto hamm_dist = ovo::hamming_32(lm_desc, keyfrm->descriptors + 32 * static_cast<size_t>(idx));
+                if (hamm_dist < best_dist) {
+                    best_dist = hamm_dist;
+                    best_idx = idx;
+                }
+            }
+        }
+        if (HAMMING_DIST_THR_LOW < best_dist) {
+            continue;
+        }
+        best_idx_of_query[i] = best_idx;
+    }
+    return 0;
+}
