@@ -4,9 +4,10 @@
  * This is the drop-in boundary for the front-end hot path of OpenVSLAM
  * (feature::orb_extractor::extract() and match::{projection,stereo,robust,bow_tree}).
  * The reference has no FFI layer for this path: it is ordinary C++ classes
- * (src/openvslam/feature/orb_extractor.h:13-150, src/openvslam/match/{projection,stereo,robust,bow_tree}.h), so every entry
- * point below cites the class member it replaces.  A header-only C++ shim that restores the
- * reference's class names on top of these functions lives in openvslam_amd/cpp/.
+ * (src/openvslam/feature/orb_extractor.h:13-150 and projection.h, stereo.h, robust.h,
+ * bow_tree.h under src/openvslam/match), so every entry point below cites the class member it
+ * replaces.  A header-only C++ shim that restores the reference's class names on top of these
+ * functions lives in openvslam_amd/cpp/.
  *
  * Conventions
  *  - plain pointers and sizes only; nothing here depends on torch, OpenCV or Eigen;
