@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void k_knn2_partial(const uint8_t* __restrict_
             qd[i] = 0;
         }
     }
-    u64 b0 = kNoKey, b1 = kNoKey;
+    // best and second best of this lane's slice of rows: rows arrive in increasing order, so strict
+    // `<` on the distance alone keeps the lowest row among equals (the 64-bit keys are only built
+    // at the end); updates become rare after the first rows, so the wave skips them with one ballot
+    u32 d0 = 0xFFFFFFFFu, d1 = 0xFFFFFFFFu, i0 = 0, i1 = 0;
     for (long long base = r0; base < r1; base += 256) {
         __syncthreads();
         {
@@ -131,11 +134,23 @@ __global__ __launch_bounds__(256) void k_knn2_partial(const uint8_t* __restrict_
             for (int i = 0; i < 8; ++i) {
                 d += __popc(qd[i] ^ r[i]);
             }
-            knn_push(((u64)d << 48) | (u64)(base + j), b0, b1);
+            if (__ballot(d < d1) != 0) {
+                const u32 row = (u32)(base - r0) + (u32)j;
+                if (d < d0) {
+                    d1 = d0;
+                    i1 = i0;
+                    d0 = d;
+                    i0 = row;
+                }
+                else if (d < d1) {
+                    d1 = d;
+                    i1 = row;
+                }
+            }
         }
     }
-    wb[wave][lane][0] = b0;
-    wb[wave][lane][1] = b1;
+    wb[wave][lane][0] = d0 == 0xFFFFFFFFu ? kNoKey : (((u64)d0 << 48) | (u64)(r0 + i0));
+    wb[wave][lane][1] = d1 == 0xFFFFFFFFu ? kNoKey : (((u64)d1 << 48) | (u64)(r0 + i1));
     __syncthreads();
     if (wave == 0 && qi < nq) {
         u64 m0 = kNoKey, m1 = kNoKey;

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the headline line of bench.py): the other configurations of the
+path at their full sizes, inputs resident in HBM, one JSON line each.
+
+  stereo   752x480 pair, 1000 keypoints per eye: 2 x extract + match::stereo        (pairs/s)
+  equirect 1920x960 frames, 4000 keypoints, rectangle masks: extract + match        (frames/s)
+  knn      2000 queries against one shard of 1250 keyframes x 2000 descriptors      (distances/s)
+"""
+import argparse
+import ctypes as C
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from openvslam_amd import _abi as A  # noqa: E402
+from openvslam_amd import _lib, synth  # noqa: E402
+from openvslam_amd.feature import orb_extractor, orb_params  # noqa: E402
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def stereo(args):
+    dev = torch.device("cuda", 0)
+    w, h, n_kp, batch = 752, 480, 1000, 64
+    fxb, fx = 47.90639384423901, 435.2046959714599
+    pairs = [synth.make_stereo_pair(w, h, seed=100 + i) for i in range(4)]
+    left = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(batch)])).to(dev)
+    right = torch.from_numpy(np.stack([pairs[i % 4][1] for i in range(batch)])).to(dev)
+    el, er = orb_extractor(orb_params(max_num_keypts=n_kp)), orb_extractor(orb_params(max_num_keypts=n_kp))
+    cap = el.keypoint_capacity(w, h)
+    bufs = [(torch.zeros((batch, cap, 7), dtype=torch.float32, device=dev), torch.zeros((batch, cap, 32), dtype=torch.uint8, device=dev),
+             torch.zeros((batch,), dtype=torch.int32, device=dev)) for _ in range(2)]
+    xr = torch.zeros((batch, cap), dtype=torch.float32, device=dev)
+    dep = torch.zeros((batch, cap), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+
+    def step():
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for ext, img, (k, d, c) in ((el, left, bufs[0]), (er, right, bufs[1])):
+            ext.extract_batch_dev(img.data_ptr(), batch, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, st)
+        for f in range(batch):
+            _lib.check(L.ovs_stereo_compute_dev(el._h, f, er._h, f, bufs[0][0][f].data_ptr(), bufs[0][1][f].data_ptr(), bufs[0][2][f:].data_ptr(),
+                                                bufs[1][0][f].data_ptr(), bufs[1][1][f].data_ptr(), bufs[1][2][f:].data_ptr(), cap,
+                                                np.float32(fxb), np.float32(fxb / fx), xr[f].data_ptr(), dep[f].data_ptr(), 0, st))
+    dt = timed(step, args.steps, args.warmup)
+    valid = float((dep > 0).sum().item()) / batch
+    return {"metric": "stereo pairs/s (2 x extract 752x480 1000 kp + match::stereo)", "value": batch / dt, "unit": "pairs/s",
+            "ms_per_step": dt * 1e3, "pairs_per_step": batch, "mean_stereo_matches_per_pair": valid}
+
+
+def equirect(args):
+    dev = torch.device("cuda", 0)
+    w, h, n_kp, batch = 1920, 960, 4000, 64
+    rects = [(0.0, 1.0, 0.0, 0.1), (0.0, 1.0, 0.84, 1.0), (0.0, 0.2, 0.7, 1.0), (0.8, 1.0, 0.7, 1.0)]
+    frames = torch.from_numpy(synth.make_sequence(w, h, batch + 1, seed=77, dx=3, dy=1)).to(dev)
+    ext = orb_extractor(orb_params(max_num_keypts=n_kp, mask_rects=rects))
+    cap = ext.keypoint_capacity(w, h)
+    n = batch + 1
+    kps = torch.zeros((n, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n,), dtype=torch.int32, device=dev)
+    reproj = torch.full((n, cap, 2), -1e38, dtype=torch.float32, device=dev)
+    matched = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    num = torch.zeros((n,), dtype=torch.int32, device=dev)
+    shift = torch.tensor([3.0, 1.0], device=dev)
+    grid = A.make_grid(0.0, 0.0, float(w), float(h))
+    sf = ext.get_scale_factors()
+    L = _lib.lib()
+
+    def step():
+        st = torch.cuda.current_stream(dev).cuda_stream
+        ext.extract_batch_dev(frames.data_ptr(), n, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, st)
+        torch.sub(kps[:-1, :, 0:2], shift, out=reproj[1:])
+        _lib.check(L.ovs_match_batch_current_and_last_dev(kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), n, cap, reproj.data_ptr(),
+                                                          C.byref(grid), A.ptr(sf, A.f32p), 8, 20.0, 1, matched.data_ptr(), num.data_ptr(), 0, st))
+    dt = timed(step, args.steps, args.warmup)
+    return {"metric": "equirectangular 1920x960 frames/s (4000 kp, rectangle masks, extract + projection match)", "value": batch / dt,
+            "unit": "frames/s", "ms_per_step": dt * 1e3, "frames_per_step": batch,
+            "mean_keypoints_per_frame": float(counts.float().mean().item()), "mean_matches_per_frame": float(num[1:].float().mean().item())}
+
+
+def knn(args):
+    dev = torch.device("cuda", 0)
+    rows, nq = 1250 * 2000, 2000
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    db = torch.randint(0, 256, (rows, 32), dtype=torch.uint8, device=dev, generator=gen)
+    q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gen)
+    out = torch.zeros(nq * 24, dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.ovs_desc_db_create(0, C.byref(h)))
+    _lib.check(L.ovs_desc_db_attach_dev(h, db.data_ptr(), rows, 0))
+
+    def step():
+        _lib.check(L.ovs_desc_db_search_dev(h, q.data_ptr(), nq, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    dt = timed(step, args.steps, args.warmup)
+    L.ovs_desc_db_destroy(h)
+    dists = rows * nq
+    return {"metric": "brute-force top-2 search, 2000 queries x 2.5 M rows (one of 8 shards)", "value": dists / dt, "unit": "distances/s",
+            "ms_per_step": dt * 1e3, "database_gbs": rows * 32 / dt / 1e9, "popcount_word_ops_per_s": dists * 8 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "all"])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    args = ap.parse_args()
+    for name in (["stereo", "equirect", "knn"] if args.workload == "all" else [args.workload]):
+        print(json.dumps(dict(workload=name, **globals()[name](args))))
+
+
+if __name__ == "__main__":
+    main()
