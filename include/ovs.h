@@ -304,6 +304,18 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
                            float focal_x_baseline, float true_baseline,
                            float* d_stereo_x_right, float* d_depths, int device, void* stream);
 
+/* stereo::compute for a batch of pairs in one set of launches: pair p is frame p of the last
+ * ovs_orb_extract_batch_dev on `left` and on `right` (both with >= n_pairs frames), keypoint /
+ * descriptor / count arrays in that call's layout (n_pairs x cap, counts per frame), outputs
+ * n_pairs x cap floats.  *d_status (device int32) becomes an OVS_ERR_* code when a keypoint's row,
+ * octave or patch falls outside the image (where the reference throws), else 0.  Enqueued on
+ * `stream`, not synchronised; n_pairs <= 65535. */
+int ovs_stereo_compute_batch_dev(ovs_orb* left, ovs_orb* right, int n_pairs,
+                                 const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_counts_left,
+                                 const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_counts_right, int cap,
+                                 float focal_x_baseline, float true_baseline,
+                                 float* d_stereo_x_right, float* d_depths, int32_t* d_status, int device, void* stream);
+
 /* ------------------------------------------------------------------------------------------ */
 /* match::robust, match::bow_tree                                                             */
 /* ------------------------------------------------------------------------------------------ */

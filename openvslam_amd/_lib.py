@@ -88,6 +88,7 @@ def _declare(L):
     L.ovs_stereo_compute.argtypes = [iv, iv, i, A.kpp, i, A.kpp, i, A.u8p, A.u8p, A.f32p, A.f32p,
                                      C.c_float, C.c_float, A.f32p, A.f32p, i]
     L.ovs_stereo_compute_dev.argtypes = [vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, i, vp]
+    L.ovs_stereo_compute_batch_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, vp, i, vp]
     L.ovs_brute_force_match.argtypes = [A.u8p, A.f32p, i, A.u8p, A.f32p, A.u8p, i, C.c_float, i, A.i32p, A.u32p, i]
     bv = C.POINTER(A.BowFeatVec)
     L.ovs_bow_match_frame_and_keyframe.argtypes = [bv, A.u8p, A.f32p, A.u8p, i, bv, A.u8p, A.f32p, i,

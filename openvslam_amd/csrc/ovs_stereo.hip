@@ -34,6 +34,10 @@ struct stereo_images {
     int lw[kMaxLevels], lh[kMaxLevels], rw[kMaxLevels], rh[kMaxLevels];
     float scale[kMaxLevels], inv_scale[kMaxLevels];
     int num_levels;
+    // batches of pairs (blockIdx.y = pair): bytes between consecutive frames of a level, and
+    // elements between consecutive pairs in the keypoint / output arrays, row tables and item lists
+    long long lfs[kMaxLevels], rfs[kMaxLevels];
+    long long kp_stride, rows_stride, items_stride;
 };
 
 __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restrict__ kr, const int* __restrict__ n_ptr, int n_fixed,
@@ -41,8 +45,12 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
                                                      int* __restrict__ err) {
     extern __shared__ u32 sm[];
     __shared__ u32 red[8];
-    const int n = n_ptr ? max(*n_ptr, 0) : n_fixed;
+    const int pair = blockIdx.y;
+    const int n = n_ptr ? min(max(n_ptr[pair], 0), n_fixed) : n_fixed;
     const int rows = im.lh[0];
+    kr += pair * im.kp_stride;
+    row_start += pair * im.rows_stride;
+    row_items += pair * im.items_stride;
     u32* cnt = sm;            // rows + 1
     u32* cur = sm + rows + 1; // rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,12 +162,22 @@ __global__ __launch_bounds__(256) void k_stereo_match(const ovs_keypoint* __rest
                                                       float focal_x_baseline, float max_disp,
                                                       float* __restrict__ out_x_right, float* __restrict__ out_depth, int* __restrict__ out_corr,
                                                       int* __restrict__ err) {
-    const int nl = nl_ptr ? max(*nl_ptr, 0) : nl_fixed;
+    const int pair = blockIdx.y;
+    const int nl = nl_ptr ? min(max(nl_ptr[pair], 0), nl_fixed) : nl_fixed;
     const int i = blockIdx.x * (256 / kSG) + threadIdx.x / kSG;
     const int gl = threadIdx.x & (kSG - 1);
     if (i >= nl) {
         return;
     }
+    kl += pair * im.kp_stride;
+    kr += pair * im.kp_stride;
+    dl += pair * im.kp_stride * 32;
+    dr += pair * im.kp_stride * 32;
+    row_start += pair * im.rows_stride;
+    row_items += pair * im.items_stride;
+    out_x_right += pair * im.kp_stride;
+    out_depth += pair * im.kp_stride;
+    out_corr += pair * im.kp_stride;
     if (gl == 0) {
         out_x_right[i] = -1.0f;
         out_depth[i] = -1.0f;
@@ -234,8 +252,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(const ovs_keypoint* __rest
         }
         return;
     }
-    const uint8_t* L = im.l[oct] + (long long)(scaled_y_left - win_size) * im.ls[oct] + (scaled_x_left - win_size);
-    const uint8_t* R = im.r[oct] + (long long)(scaled_y_left - win_size) * im.rs[oct] + (scaled_x_right - win_size);
+    const uint8_t* L = im.l[oct] + pair * im.lfs[oct] + (long long)(scaled_y_left - win_size) * im.ls[oct] + (scaled_x_left - win_size);
+    const uint8_t* R = im.r[oct] + pair * im.rfs[oct] + (long long)(scaled_y_left - win_size) * im.rs[oct] + (scaled_x_right - win_size);
     const int lc = L[win_size * im.ls[oct] + win_size];
     // every lane owns up to 8 of the 121 patch pixels
     int lv[8], pr[8], pc[8];
@@ -308,12 +326,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(const ovs_keypoint* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ nl_ptr, int nl_fixed, const int* __restrict__ corr,
+__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ nl_ptr, int nl_fixed, long long kp_stride, const int* __restrict__ corr,
                                                        float* __restrict__ x_right, float* __restrict__ depth) {
     __shared__ u32 hist[256];
     __shared__ u32 sel[4];
-    const int nl = nl_ptr ? max(*nl_ptr, 0) : nl_fixed;
+    const int pair = blockIdx.y;
+    const int nl = nl_ptr ? min(max(nl_ptr[pair], 0), nl_fixed) : nl_fixed;
     const int tid = threadIdx.x;
+    corr += pair * kp_stride;
+    x_right += pair * kp_stride;
+    depth += pair * kp_stride;
     // number of accepted matches
     hist[tid] = 0;
     __syncthreads();
@@ -381,19 +403,19 @@ int launch_stereo(const stereo_images& im, const ovs_keypoint* d_kl, const uint8
                   const ovs_keypoint* d_kr, const uint8_t* d_dr, const int* d_nr, int nr, int cap_l,
                   float focal_x_baseline, float true_baseline,
                   u32* d_row_start, u32* d_row_items, int items_cap, int* d_corr, int* d_err,
-                  float* d_x_right, float* d_depth, hipStream_t st) {
+                  float* d_x_right, float* d_depth, hipStream_t st, int n_pairs = 1) {
     const int rows = im.lh[0];
     const size_t lds = (2 * static_cast<size_t>(rows) + 1) * sizeof(u32);
     if (lds > 64 * 1024) {
         return ovs::fail(OVS_ERR_UNSUPPORTED, "images taller than 8190 rows are not supported by the stereo matcher");
     }
     const float max_disp = focal_x_baseline / true_baseline; // stereo.cc:16
-    OVS_LAUNCH("k_stereo_rows", k_stereo_rows, dim3(1), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, d_err);
+    OVS_LAUNCH("k_stereo_rows", k_stereo_rows, dim3(1, n_pairs), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, d_err);
     if (cap_l > 0) {
-        OVS_LAUNCH("k_stereo_match", k_stereo_match, dim3((cap_l + 256 / kSG - 1) / (256 / kSG)), dim3(256), 0, st,
+        OVS_LAUNCH("k_stereo_match", k_stereo_match, dim3((cap_l + 256 / kSG - 1) / (256 / kSG), n_pairs), dim3(256), 0, st,
                    d_kl, d_dl, d_nl, nl, d_kr, d_dr, im, d_row_start, d_row_items, focal_x_baseline, max_disp, d_x_right, d_depth, d_corr, d_err);
     }
-    OVS_LAUNCH("k_stereo_median", k_stereo_median, dim3(1), dim3(256), 0, st, d_nl, nl, d_corr, d_x_right, d_depth);
+    OVS_LAUNCH("k_stereo_median", k_stereo_median, dim3(1, n_pairs), dim3(256), 0, st, d_nl, nl, im.kp_stride, d_corr, d_x_right, d_depth);
     OVS_HIP(hipGetLastError());
     return OVS_OK;
 }
@@ -566,8 +588,75 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
     auto* d_corr = cv.take<int>(cap);
     auto* d_err = cv.take<int>(1);
     OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
-    return launch_stereo(im, d_kps_left, d_desc_left, d_n_left, 0, d_kps_right, d_desc_right, d_n_right, 0, cap, focal_x_baseline, true_baseline,
+    return launch_stereo(im, d_kps_left, d_desc_left, d_n_left, cap, d_kps_right, d_desc_right, d_n_right, cap, cap, focal_x_baseline, true_baseline,
                          d_row_start, d_row_items, items_cap, d_corr, d_err, d_stereo_x_right, d_depths, st);
+}
+
+int ovs_stereo_compute_batch_dev(ovs_orb* left, ovs_orb* right, int n_pairs,
+                                 const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_counts_left,
+                                 const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_counts_right, int cap,
+                                 float focal_x_baseline, float true_baseline,
+                                 float* d_stereo_x_right, float* d_depths, int32_t* d_status, int device, void* stream_) {
+    if (!left || !right || n_pairs <= 0 || n_pairs > 65535 || !d_kps_left || !d_desc_left || !d_counts_left || !d_kps_right || !d_desc_right
+        || !d_counts_right || cap <= 0 || !d_stereo_x_right || !d_depths || !d_status) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    const int num_levels = static_cast<int>(ovs_orb_get_num_scale_levels(left));
+    if (num_levels > kMaxLevels || static_cast<int>(ovs_orb_get_num_scale_levels(right)) != num_levels) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "extractors disagree on the number of levels");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    stereo_images im;
+    std::memset(&im, 0, sizeof(im));
+    im.num_levels = num_levels;
+    float sf[kMaxLevels], isf[kMaxLevels];
+    ovs_orb_get_scale_factors(left, sf);
+    ovs_orb_get_inv_scale_factors(left, isf);
+    for (int l = 0; l < num_levels; ++l) {
+        // frames of one level lie a constant number of bytes apart: take it from the first and the
+        // last pair (which also checks that both handles hold at least n_pairs frames)
+        const uint8_t* last = nullptr;
+        size_t stride = 0;
+        int w = 0, h = 0;
+        if ((rc = ovs_orb_pyramid_level_dev(left, 0, l, &im.l[l], &im.lw[l], &im.lh[l], &stride)) != OVS_OK
+            || (rc = ovs_orb_pyramid_level_dev(left, n_pairs - 1, l, &last, &w, &h, &stride)) != OVS_OK) {
+            return rc;
+        }
+        im.ls[l] = static_cast<long long>(stride);
+        im.lfs[l] = n_pairs > 1 ? (last - im.l[l]) / (n_pairs - 1) : 0;
+        if ((rc = ovs_orb_pyramid_level_dev(right, 0, l, &im.r[l], &im.rw[l], &im.rh[l], &stride)) != OVS_OK
+            || (rc = ovs_orb_pyramid_level_dev(right, n_pairs - 1, l, &last, &w, &h, &stride)) != OVS_OK) {
+            return rc;
+        }
+        im.rs[l] = static_cast<long long>(stride);
+        im.rfs[l] = n_pairs > 1 ? (last - im.r[l]) / (n_pairs - 1) : 0;
+        im.scale[l] = sf[l];
+        im.inv_scale[l] = isf[l];
+    }
+    ovs::device_guard guard(device);
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    thread_ctx* ctx = ctx_for(device, st);
+    const int items_cap = row_items_bound(cap, sf, num_levels);
+    const int rows = im.lh[0];
+    im.kp_stride = cap;
+    im.rows_stride = static_cast<long long>(al((static_cast<size_t>(rows) + 1) * 4) / 4);
+    im.items_stride = static_cast<long long>(al(static_cast<size_t>(items_cap) * 4) / 4);
+    const size_t np = static_cast<size_t>(n_pairs);
+    const size_t total = np * (static_cast<size_t>(im.rows_stride) * 4 + static_cast<size_t>(im.items_stride) * 4) + al(np * cap * 4) + al(256);
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    auto* d_row_start = cv.take<u32>(np * im.rows_stride);
+    auto* d_row_items = cv.take<u32>(np * im.items_stride);
+    auto* d_corr = cv.take<int>(np * cap);
+    OVS_HIP(hipMemsetAsync(d_status, 0, 4, st));
+    return launch_stereo(im, d_kps_left, d_desc_left, d_counts_left, cap, d_kps_right, d_desc_right, d_counts_right, cap, cap, focal_x_baseline,
+                         true_baseline, d_row_start, d_row_items, items_cap, d_corr, d_status, d_stereo_x_right, d_depths, st, n_pairs);
 }
 
 } // extern "C"

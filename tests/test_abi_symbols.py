@@ -50,7 +50,8 @@ def test_oracle_mirrors_the_compute_entry_points():
                              r"|desc_db_(create|destroy|upload|attach_dev))")
     renamed = {"ovs_orb_extract_batch_dev": "ovo_orb_extract", "ovs_orb_pyramid_level_dev": "ovo_orb_pyramid_level",
                "ovs_orb_download_pyramid_level": "ovo_orb_pyramid_level", "ovs_orb_download_blurred_level": "ovo_orb_blurred_level",
-               "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_desc_db_search": "ovo_knn2_search",
+               "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_stereo_compute_batch_dev": "ovo_stereo_compute",
+               "ovs_desc_db_search": "ovo_knn2_search",
                "ovs_desc_db_search_dev": "ovo_knn2_search", "ovs_knn2_merge_dev": "ovo_knn2_merge",
                "ovs_match_batch_current_and_last_dev": "ovo_match_batch_current_and_last"}
     missing = []

@@ -106,6 +106,66 @@ def test_stereo_compute_dev_matches_oracle():
     assert (rxr >= 0).sum() > 100
 
 
+def test_stereo_batch_equals_pair_by_pair_and_oracle():
+    """One set of launches for a batch of pairs gives, pair by pair, what the single-pair entry
+    point gives (first pair also checked against the CPU oracle)."""
+    w, h, n, pairs = 752, 480, 1000, 5
+    dev = torch.device("cuda", 0)
+    imgs = [synth.make_stereo_pair(w, h, seed=20 + p)[:2] for p in range(pairs)]
+    exts = [orb_extractor(orb_params(max_num_keypts=n), device=0) for _ in range(2)]
+    cap = exts[0].keypoint_capacity(w, h)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bufs = []
+    for side, ext in enumerate(exts):
+        d_img = torch.from_numpy(np.stack([imgs[p][side] for p in range(pairs)])).to(dev)
+        kps = torch.zeros((pairs, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((pairs, cap, 32), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((pairs,), dtype=torch.int32, device=dev)
+        ext.extract_batch_dev(d_img.data_ptr(), pairs, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, stream)
+        bufs.append((d_img, kps, desc, cnt))
+    true_baseline = np.float32(FXB / FX)
+    xr = torch.full((pairs, cap), 5.0, dtype=torch.float32, device=dev)
+    dep = torch.full((pairs, cap), 5.0, dtype=torch.float32, device=dev)
+    status = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    _lib.check(L.ovs_stereo_compute_batch_dev(exts[0]._h, exts[1]._h, pairs, bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr(),
+                                              bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), bufs[1][3].data_ptr(), cap,
+                                              np.float32(FXB), true_baseline, xr.data_ptr(), dep.data_ptr(), status.data_ptr(), 0, stream))
+    torch.cuda.synchronize(dev)
+    assert int(status.item()) == 0
+    counts = bufs[0][3].cpu().numpy()
+    for p in range(pairs):
+        xr1 = torch.zeros((cap,), dtype=torch.float32, device=dev)
+        dep1 = torch.zeros((cap,), dtype=torch.float32, device=dev)
+        _lib.check(L.ovs_stereo_compute_dev(exts[0]._h, p, exts[1]._h, p, bufs[0][1][p].data_ptr(), bufs[0][2][p].data_ptr(), bufs[0][3][p:].data_ptr(),
+                                            bufs[1][1][p].data_ptr(), bufs[1][2][p].data_ptr(), bufs[1][3][p:].data_ptr(), cap,
+                                            np.float32(FXB), true_baseline, xr1.data_ptr(), dep1.data_ptr(), 0, stream))
+        torch.cuda.synchronize(dev)
+        nl = int(counts[p])
+        assert nl > 500
+        assert _same_float(xr[p, :nl].cpu().numpy(), xr1[:nl].cpu().numpy()), p
+        assert _same_float(dep[p, :nl].cpu().numpy(), dep1[:nl].cpu().numpy()), p
+        assert (xr1[:nl] >= 0).sum().item() > 100
+        # entries past the keypoint count are not written
+        assert bool((xr[p, nl:] == 5.0).all())
+    # pair 0 against the oracle
+    ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=n), oracle.OrbExtractor(max_num_keypts=n)
+    kl, dl = ref_l.extract(imgs[0][0])
+    kr, dr = ref_r.extract(imgs[0][1])
+    la, keep_l = _views([ref_l.pyramid_level(i) for i in range(8)])
+    ra, keep_r = _views([ref_r.pyramid_level(i) for i in range(8)])
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    isf = oracle.scale_table("inv_scale_factors", 8, 1.2)
+    rxr = np.zeros(len(kl), dtype=np.float32)
+    rdep = np.zeros(len(kl), dtype=np.float32)
+    oracle.check(oracle.lib().ovo_stereo_compute(la, ra, 8, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr), A.ptr(dl, A.u8p), A.ptr(dr, A.u8p),
+                                                 A.ptr(sf, A.f32p), A.ptr(isf, A.f32p), np.float32(FXB), true_baseline,
+                                                 A.ptr(rxr, A.f32p), A.ptr(rdep, A.f32p)))
+    assert len(kl) == int(counts[0])
+    assert _same_float(xr[0, :len(kl)].cpu().numpy(), rxr)
+    assert _same_float(dep[0, :len(kl)].cpu().numpy(), rdep)
+
+
 def test_stereo_out_of_range_row_is_reported():
     img = np.zeros((64, 64), dtype=np.uint8)
     la, k1 = _views([img])

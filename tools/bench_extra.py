@@ -47,16 +47,16 @@ def stereo(args):
              torch.zeros((batch,), dtype=torch.int32, device=dev)) for _ in range(2)]
     xr = torch.zeros((batch, cap), dtype=torch.float32, device=dev)
     dep = torch.zeros((batch, cap), dtype=torch.float32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
     L = _lib.lib()
 
     def step():
         st = torch.cuda.current_stream(dev).cuda_stream
         for ext, img, (k, d, c) in ((el, left, bufs[0]), (er, right, bufs[1])):
             ext.extract_batch_dev(img.data_ptr(), batch, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, st)
-        for f in range(batch):
-            _lib.check(L.ovs_stereo_compute_dev(el._h, f, er._h, f, bufs[0][0][f].data_ptr(), bufs[0][1][f].data_ptr(), bufs[0][2][f:].data_ptr(),
-                                                bufs[1][0][f].data_ptr(), bufs[1][1][f].data_ptr(), bufs[1][2][f:].data_ptr(), cap,
-                                                np.float32(fxb), np.float32(fxb / fx), xr[f].data_ptr(), dep[f].data_ptr(), 0, st))
+        _lib.check(L.ovs_stereo_compute_batch_dev(el._h, er._h, batch, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), bufs[0][2].data_ptr(),
+                                                  bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), cap,
+                                                  np.float32(fxb), np.float32(fxb / fx), xr.data_ptr(), dep.data_ptr(), status.data_ptr(), 0, st))
     dt = timed(step, args.steps, args.warmup)
     valid = float((dep > 0).sum().item()) / batch
     return {"metric": "stereo pairs/s (2 x extract 752x480 1000 kp + match::stereo)", "value": batch / dt, "unit": "pairs/s",
