@@ -1,6 +1,6 @@
 // ovs_shim.hpp -- header-only C++ layer with the class names and member signatures of
 // feature::orb_extractor (src/openvslam/feature/orb_extractor.h:18-78) and
-// match::{projection, robust, bow_tree, stereo} (src/openvslam/match/*.h) on top of the C ABI of
+// match::{projection, robust, bow_tree, area, fuse, stereo} (src/openvslam/match/*.h) on top of the C ABI of
 // include/ovs.h.  The classes are templates over the caller's frame / keyframe / landmark /
 // matrix types and only use the member names the reference's own implementation uses
 // (landmarks_, undist_keypts_, descriptors_, stereo_x_right_, scale_factors_, camera_, ...), so in
@@ -503,6 +503,113 @@ public:
         }
         return num;
     }
+
+    // projection.cc:415-634: both directions are searched on the device, the cross-check keeps the mutual pairs
+    template <class Keyframe, class Landmark, class Mat33, class Vec3>
+    unsigned int match_keyframes_mutually(Keyframe* keyfrm_1, Keyframe* keyfrm_2, std::vector<Landmark*>& matched_lms_in_keyfrm_1,
+                                          const float& s_12, const Mat33& rot_12, const Vec3& trans_12, const float margin) const {
+        const auto rot_1w = keyfrm_1->get_rotation();
+        const auto trans_1w = keyfrm_1->get_translation();
+        const auto rot_2w = keyfrm_2->get_rotation();
+        const auto trans_2w = keyfrm_2->get_translation();
+        const auto s_rot_12 = (s_12 * rot_12).eval();
+        const auto s_rot_21 = ((1.0 / s_12) * rot_12.transpose()).eval();
+        const auto trans_21 = (-s_rot_21 * trans_12).eval();
+        const auto landmarks_1 = keyfrm_1->get_landmarks();
+        const auto landmarks_2 = keyfrm_2->get_landmarks();
+
+        std::vector<bool> is_already_matched_in_keyfrm_1(landmarks_1.size(), false);
+        std::vector<bool> is_already_matched_in_keyfrm_2(landmarks_2.size(), false);
+        for (unsigned int idx_1 = 0; idx_1 < landmarks_1.size(); ++idx_1) {
+            auto* lm = matched_lms_in_keyfrm_1.at(idx_1);
+            if (!lm) {
+                continue;
+            }
+            const auto idx_2 = lm->get_index_in_keyframe(keyfrm_2);
+            if (0 <= idx_2 && idx_2 < static_cast<int>(landmarks_2.size())) {
+                is_already_matched_in_keyfrm_1.at(idx_1) = true;
+                is_already_matched_in_keyfrm_2.at(idx_2) = true;
+            }
+        }
+        const auto s_rot_21w = (s_rot_21 * rot_1w).eval();
+        const auto trans_21w = (s_rot_21 * trans_1w + trans_21).eval();
+        const auto s_rot_12w = (s_rot_12 * rot_2w).eval();
+        const auto trans_12w = (s_rot_12 * trans_2w + trans_12).eval();
+        const std::vector<int32_t> idx2_of_1 = one_way(landmarks_1, is_already_matched_in_keyfrm_1, keyfrm_2, s_rot_21w, trans_21w, margin);
+        const std::vector<int32_t> idx1_of_2 = one_way(landmarks_2, is_already_matched_in_keyfrm_2, keyfrm_1, s_rot_12w, trans_12w, margin);
+        std::vector<int32_t> mutual(landmarks_1.size(), -1);
+        uint32_t num = 0;
+        check(ovs_cross_check(idx2_of_1.data(), static_cast<int>(idx2_of_1.size()), idx1_of_2.data(), static_cast<int>(idx1_of_2.size()),
+                              mutual.data(), &num));
+        for (size_t i = 0; i < mutual.size(); ++i) {
+            if (mutual[i] >= 0) {
+                matched_lms_in_keyfrm_1.at(i) = landmarks_2.at(mutual[i]);
+            }
+        }
+        return num;
+    }
+
+private:
+    // one direction (projection.cc:457-533): landmarks of `src` projected into `dst`; returns per
+    // source keypoint index the best keypoint of dst or -1
+    template <class LandmarkVec, class Keyframe, class Mat33, class Vec3>
+    std::vector<int32_t> one_way(const LandmarkVec& src_lms, const std::vector<bool>& already, Keyframe* dst, const Mat33& s_rot, const Vec3& trans,
+                                 const float margin) const {
+        frame_arrays fa;
+        flatten_frame(*dst, fa);
+        for (size_t i = 0; i < fa.undist_keypts.size(); ++i) {
+            fa.undist_keypts[i].octave = dst->keypts_.at(i).octave; // the level gate reads keypts_ (projection.cc:512)
+        }
+        query_arrays qa;
+        qa.reserve(src_lms.size());
+        std::vector<unsigned int> src_idx;
+        for (unsigned int idx = 0; idx < src_lms.size(); ++idx) {
+            auto* lm = src_lms.at(idx);
+            if (!lm || lm->will_be_erased() || already.at(idx)) {
+                continue;
+            }
+            const auto pos_w = lm->get_pos_in_world();
+            const auto pos_c = (s_rot * pos_w + trans).eval();
+            typename std::remove_cv<typename std::remove_reference<decltype(lm->reproj_in_tracking_)>::type>::type reproj; // Vec2_t
+            float x_right;
+            if (!dst->camera_->reproject_to_image(s_rot, trans, pos_w, reproj, x_right)) {
+                continue;
+            }
+            const auto cam_to_lm_dist = pos_c.norm();
+            if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) {
+                continue;
+            }
+            const auto pred_scale_level = lm->predict_scale_level(cam_to_lm_dist, dst);
+            const auto desc = lm->get_descriptor();
+            qa.push(reproj(0), reproj(1), x_right, static_cast<int>(pred_scale_level), 0.0f, desc, true, true);
+            src_idx.push_back(idx);
+        }
+        std::vector<int32_t> best(src_idx.size(), -1), out(src_lms.size(), -1);
+        if (!src_idx.empty()) {
+            check(ovs_match_keyframe_one_way(&fa.view, qa.finish(), margin, best.data(), device_));
+        }
+        for (size_t k = 0; k < src_idx.size(); ++k) {
+            out[src_idx[k]] = best[k];
+        }
+        return out;
+    }
+};
+
+// DBoW2::FeatureVector is a std::map<unsigned, std::vector<unsigned>>: flattened in key order
+struct bow_arrays {
+    std::vector<uint32_t> node_ids, offsets, indices;
+    ovs_bow_feat_vec v;
+    template <class FeatureVector>
+    explicit bow_arrays(const FeatureVector& fv) {
+        offsets.push_back(0);
+        for (const auto& kv : fv) {
+            node_ids.push_back(static_cast<uint32_t>(kv.first));
+            indices.insert(indices.end(), kv.second.begin(), kv.second.end());
+            offsets.push_back(static_cast<uint32_t>(indices.size()));
+        }
+        v.num_nodes = static_cast<int32_t>(node_ids.size());
+        v.node_ids = node_ids.data(); v.offsets = offsets.data(); v.indices = indices.data();
+    }
 };
 
 class robust final : public base {
@@ -537,22 +644,72 @@ public:
         }
         return num;
     }
-};
 
-// DBoW2::FeatureVector is a std::map<unsigned, std::vector<unsigned>>: flattened in key order
-struct bow_arrays {
-    std::vector<uint32_t> node_ids, offsets, indices;
-    ovs_bow_feat_vec v;
-    template <class FeatureVector>
-    explicit bow_arrays(const FeatureVector& fv) {
-        offsets.push_back(0);
-        for (const auto& kv : fv) {
-            node_ids.push_back(static_cast<uint32_t>(kv.first));
-            indices.insert(indices.end(), kv.second.begin(), kv.second.end());
-            offsets.push_back(static_cast<uint32_t>(indices.size()));
+    // robust.cc:18-172
+    template <class Keyframe, class Mat33>
+    unsigned int match_for_triangulation(Keyframe* keyfrm_1, Keyframe* keyfrm_2, const Mat33& E_12,
+                                         std::vector<std::pair<unsigned int, unsigned int>>& matched_idx_pairs) const {
+        const auto cam_center_1 = keyfrm_1->get_cam_center();
+        const auto rot_2w = keyfrm_2->get_rotation();
+        const auto trans_2w = keyfrm_2->get_translation();
+        typename std::remove_cv<typename std::remove_reference<decltype(keyfrm_2->bearings_.at(0))>::type>::type epiplane_in_keyfrm_2; // Vec3_t
+        keyfrm_2->camera_->reproject_to_bearing(rot_2w, trans_2w, cam_center_1, epiplane_in_keyfrm_2);
+        frame_arrays f1, f2;
+        flatten_frame(*keyfrm_1, f1);
+        flatten_frame(*keyfrm_2, f2);
+        const size_t n1 = f1.undist_keypts.size(), n2 = f2.undist_keypts.size();
+        std::vector<double> b1(3 * n1), b2(3 * n2);
+        for (size_t i = 0; i < n1; ++i) for (int k = 0; k < 3; ++k) b1[3 * i + k] = keyfrm_1->bearings_.at(i)(k);
+        for (size_t i = 0; i < n2; ++i) for (int k = 0; k < 3; ++k) b2[3 * i + k] = keyfrm_2->bearings_.at(i)(k);
+        const auto lms_1 = keyfrm_1->get_landmarks();
+        const auto lms_2 = keyfrm_2->get_landmarks();
+        std::vector<uint8_t> has_1(n1, 0), has_2(n2, 0);
+        for (size_t i = 0; i < n1; ++i) has_1[i] = lms_1.at(i) ? 1 : 0;
+        for (size_t i = 0; i < n2; ++i) has_2[i] = lms_2.at(i) ? 1 : 0;
+        double E[9], epipole[3];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) E[3 * i + j] = E_12(i, j);
+            epipole[i] = epiplane_in_keyfrm_2(i);
         }
-        v.num_nodes = static_cast<int32_t>(node_ids.size());
-        v.node_ids = node_ids.data(); v.offsets = offsets.data(); v.indices = indices.data();
+        const bow_arrays v1(keyfrm_1->bow_feat_vec_), v2(keyfrm_2->bow_feat_vec_);
+        std::vector<uint32_t> pairs(2 * n1 + 2);
+        uint32_t num = 0;
+        check(ovs_match_for_triangulation(&v1.v, f1.descriptors.data(), f1.undist_keypts.data(), b1.data(), f1.view.stereo_x_right, has_1.data(),
+                                          static_cast<int>(n1), &v2.v, f2.descriptors.data(), f2.undist_keypts.data(), b2.data(),
+                                          f2.view.stereo_x_right, has_2.data(), static_cast<int>(n2), E, epipole, f1.scale_factors.data(),
+                                          static_cast<int>(f1.scale_factors.size()), check_orientation_ ? 1 : 0, pairs.data(), &num, device_));
+        matched_idx_pairs.clear();
+        matched_idx_pairs.reserve(num);
+        for (uint32_t i = 0; i < num; ++i) {
+            matched_idx_pairs.emplace_back(pairs[2 * i], pairs[2 * i + 1]);
+        }
+        return num;
+    }
+
+    // robust.cc:174-207.  The eight-point RANSAC stays on the host and is the caller's class: in
+    // the reference tree EssentialSolver = solve::essential_solver (constructed from the two bearing
+    // vectors and the matches, find_via_ransac(50, false), solution_is_valid(), get_inlier_matches()).
+    template <class EssentialSolver, class Frame, class Keyframe, class Landmark>
+    unsigned int match_frame_and_keyframe(Frame& frm, Keyframe* keyfrm, std::vector<Landmark*>& matched_lms_in_frm) const {
+        const auto keyfrm_lms = keyfrm->get_landmarks();
+        unsigned int num_inlier_matches = 0;
+        matched_lms_in_frm = std::vector<Landmark*>(frm.num_keypts_, nullptr);
+        std::vector<std::pair<int, int>> matches;
+        brute_force_match(frm, keyfrm, matches);
+        EssentialSolver solver(frm.bearings_, keyfrm->bearings_, matches);
+        solver.find_via_ransac(50, false);
+        if (!solver.solution_is_valid()) {
+            return 0;
+        }
+        const auto is_inlier_matches = solver.get_inlier_matches();
+        for (unsigned int i = 0; i < matches.size(); ++i) {
+            if (!is_inlier_matches.at(i)) {
+                continue;
+            }
+            matched_lms_in_frm.at(matches.at(i).first) = keyfrm_lms.at(matches.at(i).second);
+            ++num_inlier_matches;
+        }
+        return num_inlier_matches;
     }
 };
 
@@ -617,6 +774,190 @@ public:
             }
         }
         return num;
+    }
+};
+
+// match/area.h:13-25 (monocular initializer)
+class area final : public base {
+public:
+    area(const float lowe_ratio, const bool check_orientation, int device = 0)
+        : base(lowe_ratio, check_orientation, device) {}
+
+    // area.cc:8-112
+    template <class Frame, class Point2f>
+    unsigned int match_in_consistent_area(Frame& frm_1, Frame& frm_2, std::vector<Point2f>& prev_matched_pts,
+                                          std::vector<int>& matched_indices_2_in_frm_1, int margin = 10) const {
+        static_assert(sizeof(Point2f) == 2 * sizeof(float), "cv::Point2f layout expected");
+        frame_arrays f1, f2;
+        flatten_frame(frm_1, f1);
+        flatten_frame(frm_2, f2);
+        const size_t n1 = f1.undist_keypts.size();
+        if (prev_matched_pts.size() < n1) {
+            throw std::out_of_range("prev_matched_pts is shorter than the keypoints of frame 1"); // .at() in area.cc:29
+        }
+        std::vector<float> pts(2 * n1);
+        if (n1) {
+            std::memcpy(pts.data(), static_cast<const void*>(prev_matched_pts.data()), 2 * n1 * sizeof(float));
+        }
+        std::vector<int32_t> matched(n1, -1);
+        uint32_t num = 0;
+        check(ovs_match_in_consistent_area(f1.undist_keypts.data(), f1.descriptors.data(), static_cast<int>(n1), &f2.view, pts.data(), margin,
+                                           lowe_ratio_, check_orientation_ ? 1 : 0, matched.data(), &num, device_));
+        matched_indices_2_in_frm_1.assign(matched.begin(), matched.end());
+        if (n1) {
+            std::memcpy(static_cast<void*>(prev_matched_pts.data()), pts.data(), 2 * n1 * sizeof(float));
+        }
+        return num;
+    }
+};
+
+// match/fuse.h:17-37.  The candidate search of all landmarks runs on the device in one call; the
+// landmark bookkeeping (add_observation / add_landmark / replace) then runs on the host in the
+// reference's order, re-evaluating the gates that earlier bookkeeping of the same call can close
+// (will_be_erased, is_observed_in_keyframe), so the outcome is that of the sequential loop as long
+// as a landmark is listed once.
+class fuse final : public base {
+public:
+    explicit fuse(const float lowe_ratio = 0.6, int device = 0)
+        : base(lowe_ratio, true, device) {}
+
+    // fuse.cc:12-123
+    template <class Keyframe, class Mat44, class Landmark>
+    unsigned int detect_duplication(Keyframe* keyfrm, const Mat44& Sim3_cw, const std::vector<Landmark*>& landmarks_to_check,
+                                    const float margin, std::vector<Landmark*>& duplicated_lms_in_keyfrm) const {
+        const auto s_rot_cw = Sim3_cw.template block<3, 3>(0, 0).eval();
+        const auto row0 = s_rot_cw.template block<1, 3>(0, 0).eval();
+        const auto s_cw = std::sqrt(row0.dot(row0));
+        const auto rot_cw = (s_rot_cw / s_cw).eval();
+        const auto trans_cw = (Sim3_cw.template block<3, 1>(0, 3) / s_cw).eval();
+        const auto cam_center = (-rot_cw.transpose() * trans_cw).eval();
+        duplicated_lms_in_keyfrm = std::vector<Landmark*>(landmarks_to_check.size(), nullptr);
+        const auto valid_lms_in_keyfrm = keyfrm->get_valid_landmarks();
+
+        frame_arrays fa;
+        flatten_frame(*keyfrm, fa);
+        for (size_t i = 0; i < fa.undist_keypts.size(); ++i) {
+            fa.undist_keypts[i].octave = keyfrm->keypts_.at(i).octave; // fuse.cc:83 reads keypts_
+        }
+        query_arrays qa;
+        qa.reserve(landmarks_to_check.size());
+        std::vector<unsigned int> query_of;
+        for (unsigned int i = 0; i < landmarks_to_check.size(); ++i) {
+            auto* lm = landmarks_to_check.at(i);
+            if (lm->will_be_erased() || valid_lms_in_keyfrm.count(lm)) {
+                continue;
+            }
+            if (!push_if_visible(keyfrm, lm, rot_cw, trans_cw, cam_center, qa, nullptr)) {
+                continue;
+            }
+            query_of.push_back(i);
+        }
+        std::vector<int32_t> best(query_of.size(), -1);
+        if (!query_of.empty()) {
+            check(ovs_fuse_best_candidates(&fa.view, qa.finish(), nullptr, nullptr, margin, 0, best.data(), device_));
+        }
+        unsigned int num_fused = 0;
+        for (size_t k = 0; k < query_of.size(); ++k) {
+            if (best[k] < 0) {
+                continue;
+            }
+            auto* lm = landmarks_to_check.at(query_of[k]);
+            auto* lm_in_keyfrm = keyfrm->get_landmark(best[k]);
+            if (lm_in_keyfrm) {
+                if (!lm_in_keyfrm->will_be_erased()) {
+                    duplicated_lms_in_keyfrm.at(query_of[k]) = lm_in_keyfrm;
+                }
+            }
+            else {
+                lm->add_observation(keyfrm, best[k]);
+                keyfrm->add_landmark(lm, best[k]);
+            }
+            ++num_fused;
+        }
+        return num_fused;
+    }
+
+    // fuse.cc:125-264; T = std::vector<landmark*> or std::unordered_set<landmark*>
+    template <class Keyframe, class T>
+    unsigned int replace_duplication(Keyframe* keyfrm, const T& landmarks_to_check, const float margin = 3.0) const {
+        const auto rot_cw = keyfrm->get_rotation();
+        const auto trans_cw = keyfrm->get_translation();
+        const auto cam_center = keyfrm->get_cam_center();
+        typedef typename std::remove_cv<typename std::remove_reference<decltype(*landmarks_to_check.begin())>::type>::type landmark_ptr;
+
+        frame_arrays fa;
+        flatten_frame(*keyfrm, fa);
+        std::vector<float> inv_level_sigma_sq(keyfrm->inv_level_sigma_sq_.begin(), keyfrm->inv_level_sigma_sq_.end());
+        query_arrays qa;
+        qa.reserve(landmarks_to_check.size());
+        std::vector<double> reproj_d;
+        std::vector<landmark_ptr> query_lms;
+        for (const auto lm : landmarks_to_check) {
+            if (!lm || lm->will_be_erased() || lm->is_observed_in_keyframe(keyfrm)) {
+                continue;
+            }
+            if (!push_if_visible(keyfrm, lm, rot_cw, trans_cw, cam_center, qa, &reproj_d)) {
+                continue;
+            }
+            query_lms.push_back(lm);
+        }
+        std::vector<int32_t> best(query_lms.size(), -1);
+        if (!query_lms.empty()) {
+            check(ovs_fuse_best_candidates(&fa.view, qa.finish(), reproj_d.data(), inv_level_sigma_sq.data(), margin, 1, best.data(), device_));
+        }
+        unsigned int num_fused = 0;
+        for (size_t k = 0; k < query_lms.size(); ++k) {
+            auto lm = query_lms[k];
+            if (best[k] < 0 || lm->will_be_erased() || lm->is_observed_in_keyframe(keyfrm)) {
+                continue;
+            }
+            auto* lm_in_keyfrm = keyfrm->get_landmark(best[k]);
+            if (lm_in_keyfrm) {
+                if (!lm_in_keyfrm->will_be_erased()) {
+                    if (lm->num_observations() < lm_in_keyfrm->num_observations()) {
+                        lm->replace(lm_in_keyfrm);
+                    }
+                    else {
+                        lm_in_keyfrm->replace(lm);
+                    }
+                }
+            }
+            else {
+                lm->add_observation(keyfrm, best[k]);
+                keyfrm->add_landmark(lm, best[k]);
+            }
+            ++num_fused;
+        }
+        return num_fused;
+    }
+
+private:
+    // the visibility gates shared by both functions (fuse.cc:38-65 / 146-173)
+    template <class Keyframe, class LandmarkPtr, class Mat33, class Vec3>
+    static bool push_if_visible(Keyframe* keyfrm, LandmarkPtr lm, const Mat33& rot_cw, const Vec3& trans_cw, const Vec3& cam_center,
+                                query_arrays& qa, std::vector<double>* reproj_d) {
+        const auto pos_w = lm->get_pos_in_world();
+        typename std::remove_cv<typename std::remove_reference<decltype(lm->reproj_in_tracking_)>::type>::type reproj; // Vec2_t
+        float x_right;
+        if (!keyfrm->camera_->reproject_to_image(rot_cw, trans_cw, pos_w, reproj, x_right)) {
+            return false;
+        }
+        const auto cam_to_lm_vec = (pos_w - cam_center).eval();
+        const auto cam_to_lm_dist = cam_to_lm_vec.norm();
+        if (cam_to_lm_dist < lm->get_min_valid_distance() || lm->get_max_valid_distance() < cam_to_lm_dist) {
+            return false;
+        }
+        if (cam_to_lm_vec.dot(lm->get_obs_mean_normal()) < 0.5 * cam_to_lm_dist) {
+            return false;
+        }
+        const int pred_scale_level = static_cast<int>(lm->predict_scale_level(cam_to_lm_dist, keyfrm));
+        const auto desc = lm->get_descriptor();
+        qa.push(reproj(0), reproj(1), x_right, pred_scale_level, 0.0f, desc, true, true);
+        if (reproj_d) {
+            reproj_d->push_back(reproj(0));
+            reproj_d->push_back(reproj(1));
+        }
+        return true;
     }
 };
 

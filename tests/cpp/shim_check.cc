@@ -40,7 +40,14 @@ struct mat33 {
     vec3 operator*(const vec3& x) const { vec3 r; for (int i = 0; i < 3; ++i) r.v[i] = m[i][0] * x.v[0] + m[i][1] * x.v[1] + m[i][2] * x.v[2]; return r; }
     mat33 operator/(double s) const { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = m[i][j] / s; return r; }
     template <int R, int C> vec3 block(int r0, int) const { vec3 r; for (int j = 0; j < 3; ++j) r.v[j] = m[r0][j]; return r; } // block<1, 3>
+    mat33 operator*(const mat33& o) const {
+        mat33 r;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { r.m[i][j] = 0; for (int k = 0; k < 3; ++k) r.m[i][j] += m[i][k] * o.m[k][j]; }
+        return r;
+    }
+    double operator()(int i, int j) const { return m[i][j]; }
 };
+inline mat33 operator*(double s, const mat33& a) { mat33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = s * a.m[i][j]; return r; }
 template <int R, int C> struct block_type;
 template <> struct block_type<3, 3> { typedef mat33 type; };
 template <> struct block_type<3, 1> { typedef vec3 type; };
@@ -82,7 +89,13 @@ struct camera {
         x_right = -1.0f;
         return img_bounds_.min_x_ <= reproj(0) && reproj(0) <= img_bounds_.max_x_ && img_bounds_.min_y_ <= reproj(1) && reproj(1) <= img_bounds_.max_y_;
     }
+    bool reproject_to_bearing(const mat33& rot_cw, const vec3& trans_cw, const vec3& pos_w, vec3& reproj) const {
+        const vec3 pc = rot_cw * pos_w + trans_cw;
+        reproj = pc / pc.norm();
+        return true;
+    }
 };
+struct frame;
 
 struct landmark {
     vec3 pos;
@@ -100,7 +113,16 @@ struct landmark {
     template <class F> unsigned int predict_scale_level(double, const F*) const { return static_cast<unsigned int>(level); }
     mat_u8 get_descriptor() const { return desc; }
     bool has_observation() const { return observed; }
-    bool will_be_erased() const { return false; }
+    bool erased = false;
+    bool will_be_erased() const { return erased; }
+    // observation bookkeeping, enough for match::fuse and match_keyframes_mutually
+    std::map<const frame*, int> observations;
+    int get_index_in_keyframe(const frame* kf) const { auto it = observations.find(kf); return it == observations.end() ? -1 : it->second; }
+    bool is_observed_in_keyframe(const frame* kf) const { return observations.count(kf) != 0; }
+    void add_observation(const frame* kf, int idx) { observations[kf] = idx; }
+    unsigned int num_observations() const { return static_cast<unsigned int>(observations.size()); }
+    landmark* replaced_by = nullptr;
+    void replace(landmark* lm);
 };
 
 struct frame {
@@ -116,6 +138,48 @@ struct frame {
     camera* camera_ = nullptr;
     std::map<unsigned, std::vector<unsigned>> bow_feat_vec_;
     std::vector<landmark*> get_landmarks() const { return landmarks_; }
+    // keyframe side
+    std::vector<float> inv_level_sigma_sq_;
+    std::vector<vec3> bearings_;
+    vec3 cam_center_;
+    mat33 get_rotation() const { return cam_pose_cw_.block<3, 3>(0, 0); }
+    vec3 get_translation() const { return cam_pose_cw_.block<3, 1>(0, 3); }
+    vec3 get_cam_center() const { return cam_center_; }
+    landmark* get_landmark(int idx) const { return landmarks_.at(idx); }
+    void add_landmark(landmark* lm, int idx) { landmarks_.at(idx) = lm; }
+    std::set<landmark*> get_valid_landmarks() const {
+        std::set<landmark*> out;
+        for (auto* lm : landmarks_) if (lm && !lm->will_be_erased()) out.insert(lm);
+        return out;
+    }
+};
+
+// the part of landmark::replace (data/landmark.cc:300-335) that the matchers can observe
+inline void landmark::replace(landmark* lm) {
+    if (lm == this) return;
+    const auto obs = observations;
+    observations.clear();
+    erased = true;
+    replaced_by = lm;
+    for (const auto& kv : obs) {
+        auto* kf = const_cast<frame*>(kv.first);
+        if (!lm->is_observed_in_keyframe(kf)) { kf->landmarks_.at(kv.second) = lm; lm->add_observation(kf, kv.second); }
+        else { kf->landmarks_.at(kv.second) = nullptr; }
+    }
+}
+
+struct point2f { float x, y; };
+
+// stands in for solve::essential_solver: accepts the matches whose rows agree within two pixels
+struct row_solver {
+    const std::vector<vec3>& b1; const std::vector<vec3>& b2; const std::vector<std::pair<int, int>>& matches;
+    std::vector<bool> inliers;
+    row_solver(const std::vector<vec3>& a, const std::vector<vec3>& b, const std::vector<std::pair<int, int>>& m) : b1(a), b2(b), matches(m) {}
+    void find_via_ransac(unsigned, bool) {
+        for (const auto& m : matches) inliers.push_back(std::fabs(b1.at(m.first)(1) / b1.at(m.first)(2) - b2.at(m.second)(1) / b2.at(m.second)(2)) < 2.0 / 500.0);
+    }
+    bool solution_is_valid() const { return true; }
+    std::vector<bool> get_inlier_matches() const { return inliers; }
 };
 
 } // namespace mock
@@ -168,6 +232,11 @@ int main(int argc, char** argv) {
         frm[f].landmarks_.assign(frm[f].num_keypts_, nullptr);
         frm[f].outlier_flags_.assign(frm[f].num_keypts_, false);
         frm[f].camera_ = &cam;
+        frm[f].inv_level_sigma_sq_ = ext.get_inv_level_sigma_sq();
+        for (const auto& kp : frm[f].keypts_) {
+            mock::vec3 b; b.v[0] = (kp.x - 320.0) / 500.0; b.v[1] = (kp.y - 240.0) / 500.0; b.v[2] = 1.0;
+            frm[f].bearings_.push_back(b / b.norm());
+        }
     }
     // every keypoint of frame 0 carries a landmark at depth 1 whose projection (fx = fy = 1, pose
     // = identity) into frame 1 is its pixel position shifted by -dx
@@ -198,7 +267,61 @@ int main(int argc, char** argv) {
     std::vector<mock::landmark*> bow_matched;
     for (unsigned i = 0; i < frm[1].num_keypts_; ++i) frm[1].landmarks_[i] = all_lms[i % all_lms.size()];
     const unsigned n_bow = match::bow_tree(0.75f, true).match_keyframes(&frm[0], &frm[1], bow_matched);
-    std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u\n",
-                frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow);
-    return (n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100) ? 0 : 2;
+    // brute force + (stand-in) essential-matrix inlier selection
+    std::vector<mock::landmark*> robust_matched;
+    const unsigned n_rkf = match::robust(0.75f, true).match_frame_and_keyframe<mock::row_solver>(frm[1], &frm[0], robust_matched);
+    // triangulation matches between keypoints without landmarks: frame 1 is frame 0 moved along x
+    frm[0].landmarks_.assign(frm[0].num_keypts_, nullptr);
+    frm[1].landmarks_.assign(frm[1].num_keypts_, nullptr);
+    mock::mat33 E_12;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E_12.m[i][j] = 0.0;
+    E_12.m[1][2] = -1.0; E_12.m[2][1] = 1.0;
+    frm[0].cam_center_.v[0] = 1.0;
+    std::vector<std::pair<unsigned int, unsigned int>> tri_pairs;
+    const unsigned n_tri = match::robust(0.75f, true).match_for_triangulation(&frm[0], &frm[1], E_12, tri_pairs);
+    frm[0].cam_center_.v[0] = 0.0;
+    // initializer-style area matching around the previous positions
+    std::vector<mock::point2f> prev_pts;
+    for (const auto& kp : frm[0].undist_keypts_) prev_pts.push_back({kp.x, kp.y});
+    std::vector<int> area_matched;
+    const unsigned n_area = match::area(0.9f, true).match_in_consistent_area(frm[0], frm[1], prev_pts, area_matched, 20);
+    unsigned area_moved = 0;
+    for (size_t i = 0; i < area_matched.size(); ++i) {
+        if (area_matched[i] >= 0) area_moved += prev_pts[i].x == frm[1].undist_keypts_[area_matched[i]].x && prev_pts[i].y == frm[1].undist_keypts_[area_matched[i]].y;
+    }
+    // landmarks of both keyframes: frame 0's project into frame 1 at x - dx, frame 1's into frame 0 at x + dx
+    std::vector<std::unique_ptr<mock::landmark>> lms2;
+    for (unsigned i = 0; i < frm[0].num_keypts_; ++i) { frm[0].landmarks_[i] = lms[i].get(); lms[i]->add_observation(&frm[0], static_cast<int>(i)); }
+    for (unsigned i = 0; i < frm[1].num_keypts_; ++i) {
+        lms2.emplace_back(new mock::landmark);
+        lms2.back()->pos.v[0] = frm[1].keypts_[i].x + dx; lms2.back()->pos.v[1] = frm[1].keypts_[i].y; lms2.back()->pos.v[2] = 1.0;
+        lms2.back()->desc.create(1, 32);
+        std::memcpy(lms2.back()->desc.data, frm[1].descriptors_.data + 32 * static_cast<size_t>(i), 32);
+        lms2.back()->level = frm[1].keypts_[i].octave;
+        lms2.back()->add_observation(&frm[1], static_cast<int>(i));
+        frm[1].landmarks_[i] = lms2.back().get();
+    }
+    std::vector<mock::landmark*> mutual(frm[0].num_keypts_, nullptr);
+    const float s_12 = 1.0f;
+    const unsigned n_mutual = match::projection(0.9f, true).match_keyframes_mutually(&frm[0], &frm[1], mutual, s_12, mock::mat33{}, mock::vec3{}, 7.5f);
+    unsigned mutual_written = 0;
+    for (auto* lm : mutual) mutual_written += lm != nullptr;
+    // duplicate detection, then replacement, of frame 0's landmarks inside keyframe 1
+    std::vector<mock::landmark*> duplicated;
+    const unsigned n_detect = match::fuse(0.6f).detect_duplication(&frm[1], mock::mat44{}, all_lms, 4.0f, duplicated);
+    unsigned dup_written = 0;
+    for (auto* lm : duplicated) dup_written += lm != nullptr;
+    const unsigned n_replace = match::fuse(0.6f).replace_duplication(&frm[1], all_lms, 4.0f);
+    unsigned replaced = 0, adopted = 0;
+    for (auto& lm : lms2) replaced += lm->erased;
+    for (auto& lm : lms) { replaced += lm->erased; adopted += lm->is_observed_in_keyframe(&frm[1]); }
+    std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u "
+                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u\n",
+                frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow, n_rkf, n_tri, n_area, n_mutual,
+                n_detect, n_replace, replaced, adopted);
+    const bool ok = n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100
+                    && n_rkf > 50 && n_rkf <= n_bf && n_tri == tri_pairs.size() && n_tri > 50 && n_area > 50 && area_moved == n_area
+                    && n_mutual == mutual_written && n_mutual > 100 && n_detect == dup_written && n_detect > 100 && n_replace == replaced
+                    && n_replace > 100 && adopted > 50;
+    return ok ? 0 : 2;
 }
