@@ -467,6 +467,57 @@ int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint
 int ovs_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks,
                                      int32_t* best_idx, int device);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Image preparation in front of the extractor (util::image_converter, util::stereo_rectifier)   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* camera::color_order_t (src/openvslam/camera/base.h:29-33) */
+enum { OVS_COLOR_GRAY = 0, OVS_COLOR_RGB = 1, OVS_COLOR_BGR = 2 };
+
+/* util::convert_to_grayscale (src/openvslam/util/image_converter.cc:8-39): cv::cvtColor
+ * RGB2GRAY / BGR2GRAY / RGBA2GRAY / BGRA2GRAY of 8-bit interleaved images, OpenCV 3.3.1 fixed-point
+ * rule (R 4899 + G 9617 + B 1868 + 2^13) >> 14.  channels = 3 or 4.  With color order Gray the
+ * reference leaves a multi-channel image untouched: OVS_ERR_UNSUPPORTED.
+ * Device variant: n_frames images, enqueued on `stream`, not synchronised. */
+int ovs_convert_to_grayscale_dev(const uint8_t* d_src, int n_frames, int width, int height, int channels,
+                                 size_t src_row_stride, size_t src_frame_stride, int color_order,
+                                 uint8_t* d_dst, size_t dst_row_stride, size_t dst_frame_stride,
+                                 int device, void* stream);
+int ovs_convert_to_grayscale(const uint8_t* src, int width, int height, int channels, size_t src_stride,
+                             int color_order, uint8_t* dst, size_t dst_stride, int device);
+
+/* util::equalize_histogram (src/openvslam/util/image_converter.cc:45-61): l / h = the values at
+ * positions (unsigned)(0.05 n) and (unsigned)(0.95 n) of the sorted pixels, then
+ * convertTo(CV_8U, 255.0 / (h - l), -255.0 l / (h - l)) (float multiply and add, round half to
+ * even, saturate).  8-bit images are stretched in place; 16-bit images give an 8-bit image.
+ * A frame with h == l (the reference divides by zero) is left unchanged (8 bit) / written as 0
+ * (16 bit) and d_flat_flags[frame] is set to 1, else 0.  Enqueued on `stream`. */
+int ovs_equalize_histogram_dev(uint8_t* d_img, int n_frames, int width, int height,
+                               size_t row_stride, size_t frame_stride,
+                               int32_t* d_flat_flags, int device, void* stream);
+int ovs_equalize_histogram_u16_dev(const uint16_t* d_img, int n_frames, int width, int height,
+                                   size_t row_stride, size_t frame_stride,
+                                   uint8_t* d_dst, size_t dst_row_stride, size_t dst_frame_stride,
+                                   int32_t* d_flat_flags, int device, void* stream);
+/* Host buffers; bits = 8 or 16 per source pixel; h == l returns OVS_ERR_UNSUPPORTED. */
+int ovs_equalize_histogram(const void* src, int width, int height, size_t src_stride, int bits,
+                           uint8_t* dst, size_t dst_stride, int device);
+
+/* One of the two cv::remap(..., INTER_LINEAR) calls of util::stereo_rectifier::rectify
+ * (src/openvslam/util/stereo_rectifier.cc:56-60; border constant 0): dst(x, y) = bilinear sample of
+ * src at (map_x(x, y), map_y(x, y)) with OpenCV's fixed-point rule (coordinates rounded to 1/32
+ * pixel, 15-bit weights).  The maps are the CV_32FC1 pair of cv::initUndistortRectifyMap
+ * (stereo_rectifier.cc:37-38,42-43), computed once by the caller; create converts them to fixed
+ * point and keeps them on the device (width x height = size of the rectified image). */
+typedef struct ovs_remap ovs_remap;
+int ovs_remap_create(const float* map_x, const float* map_y, int width, int height, int device, ovs_remap** out);
+void ovs_remap_destroy(ovs_remap* r);
+int ovs_remap_apply_dev(ovs_remap* r, const uint8_t* d_src, int n_frames, int src_width, int src_height,
+                        size_t src_row_stride, size_t src_frame_stride,
+                        uint8_t* d_dst, size_t dst_row_stride, size_t dst_frame_stride, void* stream);
+int ovs_remap_apply(ovs_remap* r, const uint8_t* src, int src_width, int src_height, size_t src_stride,
+                    uint8_t* dst, size_t dst_stride);
+
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points
  * keep their scratch memory per (host thread, device, stream), so independent batches may be in

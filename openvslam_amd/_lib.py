@@ -88,6 +88,17 @@ def _declare(L):
     L.ovs_stereo_compute.argtypes = [iv, iv, i, A.kpp, i, A.kpp, i, A.u8p, A.u8p, A.f32p, A.f32p,
                                      C.c_float, C.c_float, A.f32p, A.f32p, i]
     L.ovs_stereo_compute_dev.argtypes = [vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, i, vp]
+    sz = C.c_size_t
+    L.ovs_convert_to_grayscale_dev.argtypes = [vp, i, i, i, i, sz, sz, i, vp, sz, sz, i, vp]
+    L.ovs_convert_to_grayscale.argtypes = [A.u8p, i, i, i, sz, i, A.u8p, sz, i]
+    L.ovs_equalize_histogram_dev.argtypes = [vp, i, i, i, sz, sz, vp, i, vp]
+    L.ovs_equalize_histogram_u16_dev.argtypes = [vp, i, i, i, sz, sz, vp, sz, sz, vp, i, vp]
+    L.ovs_equalize_histogram.argtypes = [vp, i, i, sz, i, A.u8p, sz, i]
+    L.ovs_remap_create.argtypes = [A.f32p, A.f32p, i, i, i, C.POINTER(vp)]
+    L.ovs_remap_destroy.argtypes = [vp]
+    L.ovs_remap_destroy.restype = None
+    L.ovs_remap_apply_dev.argtypes = [vp, vp, i, i, i, sz, sz, vp, sz, sz, vp]
+    L.ovs_remap_apply.argtypes = [vp, A.u8p, i, i, sz, A.u8p, sz]
     L.ovs_stereo_compute_batch_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, vp, i, vp]
     L.ovs_brute_force_match.argtypes = [A.u8p, A.f32p, i, A.u8p, A.f32p, A.u8p, i, C.c_float, i, A.i32p, A.u32p, i]
     bv = C.POINTER(A.BowFeatVec)

@@ -164,6 +164,15 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
 int ovo_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
                              const float* inv_level_sigma_sq, float margin, int replace_mode, int32_t* best_idx_of_query);
 
+/* util::convert_to_grayscale / equalize_histogram (src/openvslam/util/image_converter.cc:8-61) and one
+ * cv::remap of util::stereo_rectifier::rectify (src/openvslam/util/stereo_rectifier.cc:56-60) */
+int ovo_convert_to_grayscale(const uint8_t* src, int width, int height, int channels, size_t src_stride, int color_order,
+                             uint8_t* dst, size_t dst_stride);
+int ovo_equalize_histogram(const void* src, int width, int height, size_t src_stride, int bits, uint8_t* dst, size_t dst_stride);
+int ovo_remap_linear(const uint8_t* src, int src_width, int src_height, size_t src_stride, const float* map_x, const float* map_y,
+                     int width, int height, uint8_t* dst, size_t dst_stride);
+void ovo_remap_linear_table(int16_t* out);
+
 /* data::landmark::compute_descriptor (src/openvslam/data/landmark.cc:127-184), batched */
 int ovo_landmark_compute_descriptors(const uint8_t* descs, const uint32_t* offsets, int n_landmarks, int32_t* best_idx);
 

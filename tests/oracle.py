@@ -112,6 +112,11 @@ def _declare(L):
     L.ovo_match_in_consistent_area.argtypes = [A.kpp, A.u8p, i, fv, A.f32p, i, C.c_float, i, A.i32p, A.u32p]
     L.ovo_landmark_compute_descriptors.argtypes = [A.u8p, A.u32p, i, A.i32p]
     L.ovo_fuse_best_candidates.argtypes = [fv, pq, A.f64p, A.f32p, C.c_float, i, A.i32p]
+    L.ovo_convert_to_grayscale.argtypes = [A.u8p, i, i, i, sz, i, A.u8p, sz]
+    L.ovo_equalize_histogram.argtypes = [C.c_void_p, i, i, sz, i, A.u8p, sz]
+    L.ovo_remap_linear.argtypes = [A.u8p, i, i, sz, A.f32p, A.f32p, i, i, A.u8p, sz]
+    L.ovo_remap_linear_table.argtypes = [C.POINTER(C.c_int16)]
+    L.ovo_remap_linear_table.restype = None
     L.ovo_knn2_search.argtypes = [A.u8p, C.c_int64, C.c_int64, A.u8p, i, A.knn2p]
     L.ovo_knn2_merge.argtypes = [A.knn2p, i, i, A.knn2p]
     L.ovo_match_batch_current_and_last.argtypes = [A.kpp, A.u8p, A.i32p, i, i, A.f32p, C.POINTER(A.Grid),

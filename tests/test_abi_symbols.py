@@ -47,10 +47,13 @@ def test_oracle_mirrors_the_compute_entry_points():
     import oracle
     L = oracle.lib()
     not_compute = re.compile(r"ovs_(last_error|device_count|timing_|orb_params_default|orb_get_|orb_keypoint_capacity|orb_level_size"
-                             r"|desc_db_(create|destroy|upload|attach_dev))")
+                             r"|desc_db_(create|destroy|upload|attach_dev)|remap_(create|destroy))")
     renamed = {"ovs_orb_extract_batch_dev": "ovo_orb_extract", "ovs_orb_pyramid_level_dev": "ovo_orb_pyramid_level",
                "ovs_orb_download_pyramid_level": "ovo_orb_pyramid_level", "ovs_orb_download_blurred_level": "ovo_orb_blurred_level",
                "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_stereo_compute_batch_dev": "ovo_stereo_compute",
+               "ovs_convert_to_grayscale_dev": "ovo_convert_to_grayscale", "ovs_equalize_histogram_dev": "ovo_equalize_histogram",
+               "ovs_equalize_histogram_u16_dev": "ovo_equalize_histogram", "ovs_remap_apply_dev": "ovo_remap_linear",
+               "ovs_remap_apply": "ovo_remap_linear",
                "ovs_desc_db_search": "ovo_knn2_search",
                "ovs_desc_db_search_dev": "ovo_knn2_search", "ovs_knn2_merge_dev": "ovo_knn2_merge",
                "ovs_match_batch_current_and_last_dev": "ovo_match_batch_current_and_last"}

@@ -5,6 +5,7 @@ path at their full sizes, inputs resident in HBM, one JSON line each.
   stereo   752x480 pair, 1000 keypoints per eye: 2 x extract + match::stereo        (pairs/s)
   equirect 1920x960 frames, 4000 keypoints, rectangle masks: extract + match        (frames/s)
   knn      2000 queries against one shard of 1250 keyframes x 2000 descriptors      (distances/s)
+  pre      BGR -> gray, rectification remap, histogram stretch on 256 raw 1241x376 frames (frames/s)
 """
 import argparse
 import ctypes as C
@@ -116,13 +117,46 @@ def knn(args):
             "ms_per_step": dt * 1e3, "database_gbs": rows * 32 / dt / 1e9, "popcount_word_ops_per_s": dists * 8 / dt}
 
 
+def pre(args):
+    """Image preparation in front of the extractor on a resident batch of raw frames: BGR -> gray,
+    histogram stretch (in place), rectification remap.  Algorithmic bytes per pixel: 4, 3 and 8."""
+    dev = torch.device("cuda", 0)
+    from openvslam_amd import util
+    w, h, batch = 1241, 376, 256
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    bgr = torch.randint(0, 256, (batch, h, w, 3), dtype=torch.uint8, device=dev, generator=gen)
+    gray = torch.zeros((batch, h, w), dtype=torch.uint8, device=dev)
+    rect = torch.zeros((batch, h, w), dtype=torch.uint8, device=dev)
+    flags = torch.zeros((batch,), dtype=torch.int32, device=dev)
+    xs, ys = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    x, y = (xs - w / 2) / (0.9 * w), (ys - h / 2) / (0.9 * w)
+    k = 1 - 0.2 * (x * x + y * y)
+    rm = util.remap((0.9 * w * 1.05 * x * k + w / 2).astype(np.float32), (0.9 * w * 1.05 * y * k + h / 2).astype(np.float32))
+    L = _lib.lib()
+    px = batch * w * h
+    out = {}
+
+    def run(name, fn, bytes_per_px):
+        dt = timed(fn, args.steps, args.warmup)
+        out[name] = {"ms": dt * 1e3, "frames_per_s": batch / dt, "algorithmic_gbs": px * bytes_per_px / dt / 1e9}
+
+    st = torch.cuda.current_stream(dev).cuda_stream
+    run("convert_to_grayscale", lambda: _lib.check(L.ovs_convert_to_grayscale_dev(bgr.data_ptr(), batch, w, h, 3, w * 3, w * h * 3, 2, gray.data_ptr(), w, w * h, 0, st)), 4)
+    run("remap", lambda: rm.apply_batch_dev(gray.data_ptr(), batch, w, h, w, w * h, rect.data_ptr(), w, w * h, st), 8)
+    run("equalize_histogram", lambda: _lib.check(L.ovs_equalize_histogram_dev(rect.data_ptr(), batch, w, h, w, w * h, flags.data_ptr(), 0, st)), 3)
+    total_ms = sum(v["ms"] for v in out.values())
+    return {"metric": "image preparation of 256 raw 1241x376 BGR frames (gray, rectify, equalize)", "value": batch / (total_ms * 1e-3), "unit": "frames/s",
+            "ms_per_step": total_ms, "stages": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "all"])
+    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "all"])
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    for name in (["stereo", "equirect", "knn"] if args.workload == "all" else [args.workload]):
+    for name in (["stereo", "equirect", "knn", "pre"] if args.workload == "all" else [args.workload]):
         print(json.dumps(dict(workload=name, **globals()[name](args))))
 
 
