@@ -165,6 +165,216 @@ __global__ __launch_bounds__(256) void k_knn2_partial(const uint8_t* __restrict_
     }
 }
 
+// ---- the same search on the matrix cores ------------------------------------------------------------
+// With query bits as +1 / -1 bytes and database bits as 1 / 0 bytes the integer dot product over the
+// 256 bit positions is D = |q and r| - |not q and r|, and the Hamming distance is |q| - D, so a tile
+// of 16 rows x 16 queries is four v_mfma_i32_16x16x64_i8.  A workgroup of four waves shares the
+// expanded rows through LDS (double buffered, stored in fragment order: one ds_read_b128 per lane and
+// fragment, conflict free); every wave keeps its own 128 queries as B fragments in registers.  The
+// accumulator layout puts a query on the lane (column = lane & 15) and four consecutive rows in the
+// four registers, so the serial best / second-best rule runs per lane on D (larger D = smaller
+// distance; strict '>' keeps the lowest row among equals); a wave skips a tile with one compare of
+// the tile maximum when no lane improves.  The four lane groups of a query, the row slices and the
+// shards are merged with the (distance, row) keys as before.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr int kMmRows = 64;          // database rows per iteration (four 16-row tiles)
+constexpr int kMmChunks = kMmRows * 16 / 256; // 16-bit chunks each thread expands per iteration
+#ifndef OVS_MM_TILES
+#define OVS_MM_TILES 4
+#define OVS_MM_OCC 3
+#endif
+constexpr int kMmTiles = OVS_MM_TILES; // 16-query tiles per wave
+constexpr int kMmBlocksPerCu = OVS_MM_OCC;
+constexpr int kMmQueriesPerWave = 16 * kMmTiles, kMmQueriesPerBlock = 4 * kMmQueriesPerWave;
+constexpr int kMmMaxSliceRows = 1 << 30;
+constexpr int kMmNoD = -(1 << 20);
+
+// 16 bits -> 16 bytes of 0 / 1 (bit 4 j + e -> byte e of dword j)
+__device__ __forceinline__ v4i expand16(u32 bits16) {
+    v4i v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = (int)(__umul24((bits16 >> (4 * j)) & 15u, 0x00204081u) & 0x01010101u);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256, kMmBlocksPerCu) void k_knn2_mfma(const uint8_t* __restrict__ db, long long n_rows, int rows_per_slice,
+                                                      const uint8_t* __restrict__ queries, int nq, u64* __restrict__ partial /* [slices][nq][2] */) {
+    __shared__ v4i atile[2][16 * kMmRows];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int q0 = blockIdx.x * kMmQueriesPerBlock + wave * kMmQueriesPerWave;
+    const long long r0 = (long long)blockIdx.y * rows_per_slice;
+    const long long r1 = min(r0 + (long long)rows_per_slice, n_rows);
+    const int nblk = (int)((r1 - r0 + kMmRows - 1) / kMmRows);
+
+    // B fragments: query q0 + 16 t + n, k step s: bits [64 s + 16 kq, + 16) as +1 (bit set) / -1 bytes
+    v4i bq[kMmTiles][4];
+    int pq[kMmTiles];
+#pragma unroll
+    for (int t = 0; t < kMmTiles; ++t) {
+        const int qi = q0 + 16 * t + n;
+        u32 qd[8];
+        if (qi < nq) {
+            load_desc(queries + 32 * (size_t)qi, qd);
+        }
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                qd[i] = 0;
+            }
+        }
+        pq[t] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            pq[t] += __popc(qd[i]);
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const u32 pair = (kq & 2) ? qd[2 * sidx + 1] : qd[2 * sidx];
+            const v4i e = expand16((pair >> (16 * (kq & 1))) & 0xFFFFu);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bq[t][sidx][j] = qi < nq ? (int)~((u32)e[j] * 0xFEu) : 0;
+            }
+        }
+    }
+    // per lane: best / second best (D and row offset inside the slice) among the rows this lane group
+    // has seen, and thr = the query's second-best D over all four lane groups as of its last update.
+    // A row can only enter the query's final top two if its D exceeds thr (rows arrive in increasing
+    // order, so an equal D from a later row loses), which makes thr an exact and much tighter gate
+    // than the lane's own second best.
+    int D0[kMmTiles], D1[kMmTiles], thr[kMmTiles];
+    u32 I0[kMmTiles], I1[kMmTiles];
+#pragma unroll
+    for (int t = 0; t < kMmTiles; ++t) {
+        D0[t] = D1[t] = thr[t] = kMmNoD;
+        I0[t] = I1[t] = 0;
+    }
+
+    // expansion: a block of kMmRows rows is 16 * kMmRows chunks of 16 bits, one per LDS slot.  Wave w
+    // fills the fragments of k step w of every 16-row tile, lane l the slot it will later be read
+    // from by lane l (row l & 15, halfword 4 w + (l >> 4)): a wave writes 1 KB of consecutive LDS.
+    // The bits are fetched two iterations ahead of their use.
+    const uint16_t* db16 = reinterpret_cast<const uint16_t*>(db);
+    const u32 slice_rows = (u32)(r1 - r0);
+    static_assert(kMmChunks == kMmRows / 16, "one chunk per thread and 16-row tile");
+    const int exp_slot = (wave << 6) + lane, exp_hw = 4 * wave + kq;
+    auto load_bits = [&](int blk, u32* out) {
+#pragma unroll
+        for (int c = 0; c < kMmChunks; ++c) {
+            const u32 row = (u32)blk * kMmRows + 16u * c + (u32)n;
+            out[c] = (blk < nblk && row < slice_rows) ? (u32)db16[(r0 + row) * 16 + exp_hw] : 0u;
+        }
+    };
+    int slot[kMmChunks];
+#pragma unroll
+    for (int c = 0; c < kMmChunks; ++c) {
+        slot[c] = (c << 8) + exp_slot;
+    }
+    u32 bits0[kMmChunks], bits1[kMmChunks];
+    load_bits(0, bits0);
+#pragma unroll
+    for (int c = 0; c < kMmChunks; ++c) {
+        atile[0][slot[c]] = expand16(bits0[c]);
+    }
+    load_bits(1, bits0);
+    load_bits(2, bits1);
+    __syncthreads();
+#pragma unroll 1
+    for (int b = 0; b < nblk; ++b) {
+        const int cur = b & 1;
+        if (b + 1 < nblk) {
+#pragma unroll
+            for (int c = 0; c < kMmChunks; ++c) {
+                atile[cur ^ 1][slot[c]] = expand16(bits0[c]);
+                bits0[c] = bits1[c];
+            }
+            load_bits(b + 3, bits1);
+        }
+        const bool full = (u32)(b + 1) * kMmRows <= slice_rows;
+        u32 dirty = 0; // tiles whose best / second best changed in this iteration (wave uniform)
+#pragma unroll
+        for (int mt = 0; mt < kMmRows / 16; ++mt) {
+            v4i af[4];
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                af[sidx] = atile[cur][((mt * 4 + sidx) << 6) + lane];
+            }
+            // all tiles' products first, then the selection: the matrix pipe works on the later
+            // tiles while the vector unit handles the earlier ones
+            v4i acc[kMmTiles];
+#pragma unroll
+            for (int t = 0; t < kMmTiles; ++t) {
+                acc[t] = v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    acc[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[sidx], bq[t][sidx], acc[t], 0, 0, 0);
+                }
+            }
+            // accumulator register i of lane group kq is row 4 kq + i of the 16-row tile
+            const u32 row_b = (u32)b * kMmRows + 16u * mt + 4u * kq;
+#pragma unroll
+            for (int t = 0; t < kMmTiles; ++t) {
+                const int m = max(max(acc[t][0], acc[t][1]), max(acc[t][2], acc[t][3]));
+                if (__ballot(m > thr[t]) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32 row = row_b + i;
+                        int D = acc[t][i];
+                        if (!full) {
+                            D = row < slice_rows ? D : kMmNoD;
+                        }
+                        const bool gt0 = D > D0[t], gt1 = D > D1[t];
+                        D1[t] = gt0 ? D0[t] : (gt1 ? D : D1[t]);
+                        I1[t] = gt0 ? I0[t] : (gt1 ? row : I1[t]);
+                        D0[t] = gt0 ? D : D0[t];
+                        I0[t] = gt0 ? row : I0[t];
+                    }
+                    dirty |= 1u << t;
+                }
+            }
+        }
+        // refresh the gate of the tiles that changed: second best of the query over its four lane groups
+#pragma unroll
+        for (int t = 0; t < kMmTiles; ++t) {
+            if (dirty & (1u << t)) {
+                int a0 = D0[t], a1 = D1[t];
+#pragma unroll
+                for (int d = 16; d <= 32; d <<= 1) {
+                    const int b0 = __shfl_xor(a0, d), b1 = __shfl_xor(a1, d);
+                    const int n1 = max(min(a0, b0), max(a1, b1));
+                    a0 = max(a0, b0);
+                    a1 = n1;
+                }
+                thr[t] = a1;
+            }
+        }
+        __syncthreads();
+    }
+    // the four lane groups of a query hold disjoint rows: merge and write the slice's result
+#pragma unroll
+    for (int t = 0; t < kMmTiles; ++t) {
+        u64 k0 = D0[t] == kMmNoD ? kNoKey : (((u64)(u32)(pq[t] - D0[t]) << 48) | (u64)(r0 + I0[t]));
+        u64 k1 = D1[t] == kMmNoD ? kNoKey : (((u64)(u32)(pq[t] - D1[t]) << 48) | (u64)(r0 + I1[t]));
+#pragma unroll
+        for (int d = 16; d <= 32; d <<= 1) {
+            const u64 o0 = ((u64)__shfl_xor((u32)(k0 >> 32), d) << 32) | __shfl_xor((u32)k0, d);
+            const u64 o1 = ((u64)__shfl_xor((u32)(k1 >> 32), d) << 32) | __shfl_xor((u32)k1, d);
+            knn_push(o0, k0, k1);
+            knn_push(o1, k0, k1);
+        }
+        const int qi = q0 + 16 * t + n;
+        if (kq == 0 && qi < nq) {
+            u64* o = partial + ((size_t)blockIdx.y * nq + qi) * 2;
+            o[0] = k0;
+            o[1] = k1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_knn2_finish(const u64* __restrict__ partial, int slices, int nq, long long row_offset,
                                                      ovs_knn2* __restrict__ out) {
     const int qi = blockIdx.x * 256 + threadIdx.x;
@@ -421,13 +631,35 @@ int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ov
     }
     ovs::device_guard guard(db->device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    const int slices = static_cast<int>(std::max<long long>(1, (db->n_rows + kKnnRowsPerBlock - 1) / kKnnRowsPerBlock));
+    // 128 queries and more: matrix-core kernel, row slices sized so that the grid is about two
+    // workgroups per compute unit (long slices keep the per-lane best / second best warm)
+    const bool mfma = nq >= 128 && db->n_rows > 0;
+    int slices, rows_per_slice = kKnnRowsPerBlock;
+    if (mfma) {
+        const int qblocks = (nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock;
+        const long long want = std::max<long long>(1, 256 * kMmBlocksPerCu / qblocks);
+        const long long by_rows = std::max<long long>(1, (db->n_rows + 1023) / 1024);
+        const long long ns = std::min(want, by_rows);
+        long long rps = (db->n_rows + ns - 1) / ns;
+        rps = std::min<long long>((rps + kMmRows - 1) / kMmRows * kMmRows, kMmMaxSliceRows);
+        rows_per_slice = static_cast<int>(rps);
+        slices = static_cast<int>((db->n_rows + rps - 1) / rps);
+    }
+    else {
+        slices = static_cast<int>(std::max<long long>(1, (db->n_rows + kKnnRowsPerBlock - 1) / kKnnRowsPerBlock));
+    }
     int rc = db->partial.reserve(static_cast<size_t>(slices) * nq * 2 * sizeof(u64));
     if (rc != OVS_OK) {
         return rc;
     }
-    OVS_LAUNCH("k_knn2_partial", k_knn2_partial, dim3((nq + 63) / 64, slices), dim3(256), 0, st,
-               db->d_rows, db->n_rows, d_queries, nq, db->partial.as<u64>());
+    if (mfma) {
+        OVS_LAUNCH("k_knn2_mfma", k_knn2_mfma, dim3((nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock, slices), dim3(256), 0, st,
+                   db->d_rows, db->n_rows, rows_per_slice, d_queries, nq, db->partial.as<u64>());
+    }
+    else {
+        OVS_LAUNCH("k_knn2_partial", k_knn2_partial, dim3((nq + 63) / 64, slices), dim3(256), 0, st,
+                   db->d_rows, db->n_rows, d_queries, nq, db->partial.as<u64>());
+    }
     OVS_LAUNCH("k_knn2_finish", k_knn2_finish, dim3((nq + 255) / 256), dim3(256), 0, st,
                db->partial.as<u64>(), slices, nq, db->row_offset, d_out);
     OVS_HIP(hipGetLastError());
