@@ -248,6 +248,9 @@ struct query_ctx {
     double rxd, ryd;
 };
 
+// FUSE: the two match::fuse kinds are compiled in (separate kernel instances keep their double-
+// precision state and gates out of the tracking matchers' kernels)
+template <bool FUSE>
 __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const frame_dev& f, const query_dev& q, int qi, query_ctx& c) {
     c.ranged = false;
     c.lo = c.hi = 0;
@@ -303,17 +306,21 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
         case kFuseDetect:
             c.min_level = -1;
             c.max_level = -1;
-            c.fuse = 1;
+            if (FUSE) {
+                c.fuse = 1;
+            }
             break;
         case kFuseReplace:
             c.min_level = -1;
             c.max_level = -1;
             c.ugate = true;
-            c.fuse = 2;
-            c.rxd = q.reproj_xy_d[2 * qi];
-            c.ryd = q.reproj_xy_d[2 * qi + 1];
-            c.rx = (float)c.rxd; // get_keypoints_in_cell takes floats: the doubles narrow at the call
-            c.ry = (float)c.ryd;
+            if (FUSE) {
+                c.fuse = 2;
+                c.rxd = q.reproj_xy_d[2 * qi];
+                c.ryd = q.reproj_xy_d[2 * qi + 1];
+                c.rx = (float)c.rxd; // get_keypoints_in_cell takes floats: the doubles narrow at the call
+                c.ry = (float)c.ryd;
+            }
             break;
         default:
             c.min_level = -1;
@@ -331,6 +338,7 @@ __device__ __forceinline__ u32 key_idx(u64 k) { return (u32)(k & 0xFFFFFu); }
 
 // window / level gates of get_keypoints_in_cell (common.cc:166-178) + the per-candidate gates of
 // the projection loops that do not depend on earlier queries
+template <bool FUSE>
 __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx& c, const uint4& en, const uint8_t* occupied, const u32* blocked,
                                              bool matcher_gates) {
     if (c.ranged) {
@@ -380,13 +388,13 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
             }
         }
     }
-    if (c.fuse == 1) {
+    if (FUSE && c.fuse == 1) {
         // int scale_level, int pred_scale_level (fuse.cc:68,83-88)
         if (oct < (int)c.sl - 1 || (int)c.sl < oct) {
             return false;
         }
     }
-    else if (c.fuse == 2) {
+    else if (FUSE && c.fuse == 2) {
         // fuse.cc:198-222: reproj is double, keypoint and x_right are float; products and sums in the
         // reference's order without contraction
         const double e_x = __dsub_rn(c.rxd, (double)__uint_as_float(en.x));
@@ -408,7 +416,7 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
 
 // Scan of one query window by a group of G lanes that share the query.  Returns (in every lane of
 // the group) the K smallest keys among the keypoints that pass all gates; `total` counts them.
-template <int G, int K>
+template <int G, int K, bool FUSE>
 __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* qd, const uint8_t* occupied,
                             const u32* blocked, u64 (&top)[K], u32& total) {
     const int gl = threadIdx.x & (G - 1);
@@ -471,7 +479,7 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
             if (t < T) {
                 const u32 j = cs + (t - cexc);
                 const uint4 en = f.g_entry[j];
-                if (passes_gates(f, c, en, occupied, blocked, true)) {
+                if (passes_gates<FUSE>(f, c, en, occupied, blocked, true)) {
                     const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
                     const u32 dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w)
                                      + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
@@ -505,6 +513,7 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
     }
 }
 
+template <bool FUSE>
 __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __restrict__ problems, proj_params pp) {
     const proj_problem& P = problems[blockIdx.y];
     constexpr int QPB = 256 / kGroup;
@@ -521,10 +530,10 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
     }
     query_ctx c;
     if (P.q.valid[qi]) {
-        if (make_query_ctx(pp, P.frm, P.q, qi, c)) {
+        if (make_query_ctx<FUSE>(pp, P.frm, P.q, qi, c)) {
             u32 qd[8];
             load_desc(P.q.desc + 32 * (size_t)qi, qd);
-            window_topk<kGroup, kTopK>(P.frm, c, qd, P.occupied, nullptr, top, total);
+            window_topk<kGroup, kTopK, FUSE>(P.frm, c, qd, P.occupied, nullptr, top, total);
         }
         else if (gl == 0) {
             *P.err = OVS_ERR_OUT_OF_RANGE;
@@ -588,7 +597,7 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
 // change its outcome is handled alone with a full rescan of its window.
 // IN_LDS: the per-keypoint `matched` and `claim` arrays fit in LDS next to the bitmap; otherwise
 // they stay in global memory and queries are retired one per round.
-template <bool IN_LDS>
+template <bool IN_LDS, bool FUSE>
 __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp, int lds_n) {
     extern __shared__ u32 sm[];
     __shared__ u32 hist[32];
@@ -622,28 +631,44 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr
                                              : ((pp.kind == kSim3 || pp.kind == kRange || pp.kind == kFuseDetect || pp.kind == kFuseReplace) ? kThrLow : kThrHigh);
     u32 mynum = 0;
-    for (int base = 0; base < nq; base += 64) {
-        const int mq = base + lane;
-        u64 mykeys[kTopK];
-        u32 mytot = 0;
-        bool done = true;
-        bool blocks = true;
+    // the candidate list, count and flags of a chunk's query are fetched while the previous chunk is
+    // being resolved
+    u64 nkeys[kTopK];
+    u32 ntot = 0;
+    bool ndone = true, nblocks = true;
+    auto fetch = [&](int q) {
 #pragma unroll
         for (int k = 0; k < kTopK; ++k) {
-            mykeys[k] = kNoKey;
+            nkeys[k] = kNoKey;
         }
-        if (mq < nq) {
-            mytot = P.totals[mq];
-            done = !P.q.valid[mq] || mytot == 0;
-            const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(P.lists + (size_t)mq * kTopK);
+        ntot = 0;
+        ndone = true;
+        nblocks = true;
+        if (q < nq) {
+            ntot = P.totals[q];
+            ndone = !P.q.valid[q] || ntot == 0;
+            const ulonglong2* lp = reinterpret_cast<const ulonglong2*>(P.lists + (size_t)q * kTopK);
 #pragma unroll
             for (int k = 0; k < kTopK / 2; ++k) {
                 const ulonglong2 v = lp[k];
-                mykeys[2 * k] = v.x;
-                mykeys[2 * k + 1] = v.y;
+                nkeys[2 * k] = v.x;
+                nkeys[2 * k + 1] = v.y;
             }
-            blocks = (pp.kind == kFrameKeyfrm || pp.kind == kSim3 || pp.kind == kRange) ? true : (P.q.has_obs ? P.q.has_obs[mq] != 0 : true);
+            nblocks = (pp.kind == kFrameKeyfrm || pp.kind == kSim3 || pp.kind == kRange) ? true : (P.q.has_obs ? P.q.has_obs[q] != 0 : true);
         }
+    };
+    fetch(lane);
+    for (int base = 0; base < nq; base += 64) {
+        const int mq = base + lane;
+        u64 mykeys[kTopK];
+#pragma unroll
+        for (int k = 0; k < kTopK; ++k) {
+            mykeys[k] = nkeys[k];
+        }
+        const u32 mytot = ntot;
+        bool done = ndone;
+        const bool blocks = nblocks;
+        fetch(mq + 64);
         int myacc = -1;
         while (true) {
             u64 best = kNoKey, second = kNoKey;
@@ -744,12 +769,12 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
             if (stop == first_rescan) {
                 const int qi = base + stop;
                 query_ctx c;
-                make_query_ctx(pp, P.frm, P.q, qi, c);
+                make_query_ctx<FUSE>(pp, P.frm, P.q, qi, c);
                 u32 qd[8];
                 load_desc(P.q.desc + 32 * (size_t)qi, qd);
                 u64 top2[2];
                 u32 t2;
-                window_topk<64, 2>(P.frm, c, qd, P.occupied, blocked, top2, t2);
+                window_topk<64, 2, FUSE>(P.frm, c, qd, P.occupied, blocked, top2, t2);
                 if (top2[0] != kNoKey && accept_rule(pp, P.frm, top2[0], top2[1])) {
                     const u32 ridx = key_idx(top2[0]);
                     const bool rblocks = __shfl((int)blocks, stop) != 0;
@@ -784,16 +809,39 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     if (orient) {
         // rotation consistency, match/angle_checker.h: keep the three fullest of 30 bins.  Every lane
         // revisits exactly the queries it wrote acc_idx for.
-        for (int qi = lane; qi < nq; qi += 64) {
-            const int idx = P.acc_idx[qi];
-            if (0 <= idx) {
-                const float qa = P.q.angle[qi], ca = P.frm.kps[idx].angle;
-                int bin = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa, ca) : __fsub_rn(ca, qa));
-                if (bin < 0 || 30 <= bin) {
-                    *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
-                    bin = 0;
+        // Both passes gather (accepted index -> keypoint angle): eight independent queries per lane
+        // are in flight at a time, the loads of a group are issued before any of them is used.
+        constexpr int U = 8;
+        auto bins_of = [&](int q0, int (&idx)[U], int (&bin)[U]) {
+            float qa[U], ca[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int qi = q0 + 64 * u;
+                idx[u] = qi < nq ? P.acc_idx[qi] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int qi = q0 + 64 * u;
+                qa[u] = 0 <= idx[u] ? P.q.angle[qi] : 0.0f;
+                ca[u] = 0 <= idx[u] ? P.frm.kps[idx[u]].angle : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bin[u] = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa[u], ca[u]) : __fsub_rn(ca[u], qa[u]));
+            }
+        };
+        for (int q0 = lane; q0 < nq; q0 += 64 * U) {
+            int idx[U], bin[U];
+            bins_of(q0, idx, bin);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (0 <= idx[u]) {
+                    if (bin[u] < 0 || 30 <= bin[u]) {
+                        *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
+                        bin[u] = 0;
+                    }
+                    atomicAdd(&hist[bin[u]], 1u);
                 }
-                atomicAdd(&hist[bin], 1u);
             }
         }
         __syncthreads();
@@ -803,23 +851,25 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         __syncthreads();
         const u32 v0 = order[0], v1 = order[1], v2 = order[2];
         u32 removed = 0;
-        for (int qi = lane; qi < nq; qi += 64) {
-            const int idx = P.acc_idx[qi];
-            if (0 <= idx) {
-                const float qa = P.q.angle[qi], ca = P.frm.kps[idx].angle;
-                int bin = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa, ca) : __fsub_rn(ca, qa));
-                bin = (bin < 0 || 30 <= bin) ? 0 : bin;
-                if ((u32)bin != v0 && (u32)bin != v1 && (u32)bin != v2) {
-                    if (pp.per_query_output) {
-                        P.acc_idx[qi] = -1;
+        for (int q0 = lane; q0 < nq; q0 += 64 * U) {
+            int idx[U], bin[U];
+            bins_of(q0, idx, bin);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (0 <= idx[u]) {
+                    const int b = (bin[u] < 0 || 30 <= bin[u]) ? 0 : bin[u];
+                    if ((u32)b != v0 && (u32)b != v1 && (u32)b != v2) {
+                        if (pp.per_query_output) {
+                            P.acc_idx[q0 + 64 * u] = -1;
+                        }
+                        else if (IN_LDS) {
+                            lmatched[idx[u]] = -2;
+                        }
+                        else {
+                            P.matched[idx[u]] = -2;
+                        }
+                        ++removed;
                     }
-                    else if (IN_LDS) {
-                        lmatched[idx] = -2;
-                    }
-                    else {
-                        P.matched[idx] = -2;
-                    }
-                    ++removed;
                 }
             }
         }
@@ -874,7 +924,7 @@ __global__ __launch_bounds__(256) void k_window_list(frame_dev f, int nq, const 
                 uint4 en = make_uint4(0, 0, 0, 0);
                 if (j < e) {
                     en = f.g_entry[j];
-                    pass = passes_gates(f, c, en, nullptr, nullptr, false);
+                    pass = passes_gates<false>(f, c, en, nullptr, nullptr, false);
                 }
                 const u64 bits = __ballot(pass);
                 if (pass && out) {
@@ -979,20 +1029,36 @@ size_t resolve_lds_bytes(int n, int lds_n) {
     return (static_cast<size_t>((n + 31) / 32) + 1) * 4;
 }
 
-int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
+template <bool FUSE>
+int launch_resolve_t(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
     const int lds_n = resolve_lds_n(max_n);
     const size_t bytes = resolve_lds_bytes(max_n, lds_n);
     if (lds_n > 0) {
-        OVS_LAUNCH("k_proj_resolve", k_proj_resolve<true>, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
     }
     else {
         if (bytes > 64 * 1024) {
-            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve<false, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         static_cast<int>(bytes)));
         }
-        OVS_LAUNCH("k_proj_resolve", k_proj_resolve<false>, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, 0);
+        OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<false, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, 0);
     }
     return OVS_OK;
+}
+
+bool kind_is_fuse(int kind) { return kind == kFuseDetect || kind == kFuseReplace; }
+
+int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
+    return kind_is_fuse(pp.kind) ? launch_resolve_t<true>(d_prob, n_problems, max_n, pp, st) : launch_resolve_t<false>(d_prob, n_problems, max_n, pp, st);
+}
+
+void launch_candidates(dim3 grid, const proj_problem* d_prob, const proj_params& pp, hipStream_t st) {
+    if (kind_is_fuse(pp.kind)) {
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<true>, grid, dim3(256), 0, st, d_prob, pp);
+    }
+    else {
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<false>, grid, dim3(256), 0, st, d_prob, pp);
+    }
 }
 
 int grid_lds_bytes(const ovs_grid& g) { return static_cast<int>((2 * g.num_cols * g.num_rows + 1) * sizeof(u32)); }
@@ -1170,7 +1236,7 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
 
     if (nq) {
         constexpr int QPB = 256 / kGroup;
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((nq + QPB - 1) / QPB, 1), dim3(256), 0, st, d_prob, pp);
+        launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
     }
     if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
         return rc;
@@ -1318,7 +1384,7 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
     }
     if (nq) {
         constexpr int QPB = 256 / kGroup;
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((nq + QPB - 1) / QPB, 1), dim3(256), 0, st, d_prob, pp);
+        launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
     }
     if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
         return rc;
@@ -1764,7 +1830,7 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
                d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
     if (n_frames > 1) {
         constexpr int QPB = 256 / kGroup;
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates, dim3((cap + QPB - 1) / QPB, n_frames - 1), dim3(256), 0, st, d_prob, pp);
+        launch_candidates(dim3((cap + QPB - 1) / QPB, n_frames - 1), d_prob, pp, st);
         if ((rc = launch_resolve(d_prob, n_frames - 1, cap, pp, st)) != OVS_OK) {
             return rc;
         }
