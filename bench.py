@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frames matched per step and GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1, help="sub-batches in flight on separate HIP streams (each re-extracts one halo frame)")
+    ap.add_argument("--streams", type=int, default=2, help="contiguous sub-batches of the step's batch in flight on separate HIP streams (each re-extracts one halo frame)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -282,13 +282,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": "KITTI-shaped 1241x376 mono batch, 2000 kp, 8 levels, scale 1.2, "
                                "extract + match::projection (current vs last frame, margin 20, orientation check)",
-                   "frames_per_step_per_gpu": args.batch, "halo_frames_per_step": 1,
+                   "frames_per_step_per_gpu": args.batch, "halo_frames_per_step": args.streams, "streams": args.streams,
                    "mean_keypoints_per_frame": float(counts.mean()), "mean_matches_per_frame": float(nm[1:].mean())},
     }
 
     if rank == 0:
         # per-kernel device time of the same step (separate, untimed pass with event pairs around
-        # every launch on the launch stream)
+        # every launch on the launch stream; the whole batch on ONE stream, so that no other kernel
+        # shares the device while a launch is being timed)
         L = _lib.lib()
         L.ovs_timing_reset()
         L.ovs_timing_enable(1)

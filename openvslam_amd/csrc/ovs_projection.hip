@@ -597,6 +597,15 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
 // change its outcome is handled alone with a full rescan of its window.
 // IN_LDS: the per-keypoint `matched` and `claim` arrays fit in LDS next to the bitmap; otherwise
 // they stay in global memory and queries are retired one per round.
+// The resolve kernel is one wavefront per workgroup: LDS traffic of a single wave is processed in
+// order, so a point where all lanes must see each other's LDS writes needs the LDS counter drained
+// and the compiler kept from moving accesses across it, not s_barrier (whose preceding full wait
+// would also stall on the global loads that are deliberately left in flight).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool IN_LDS, bool FUSE>
 __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp, int lds_n) {
     extern __shared__ u32 sm[];
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
             P.matched[i] = -1;
         }
     }
-    __syncthreads();
+    wave_sync();
 
     const bool excl = !kind_is_one_way(pp.kind);
     const int needed = (pp.kind == kFrameLms || pp.kind == kRange) ? 2 : 1;
@@ -723,7 +732,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 if (part) {
                     atomicMin(&claim[bidx], (u32)lane);
                 }
-                __syncthreads();
+                wave_sync();
                 bool conflict = false;
                 if (live && lane < first_rescan) {
                     conflict = claim[bidx] < (u32)lane;
@@ -734,7 +743,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 const u64 cmask = __ballot(conflict);
                 const int first_conflict = cmask ? __ffsll((long long)cmask) - 1 : 64;
                 stop = min(first_rescan, first_conflict);
-                __syncthreads();
+                wave_sync();
                 if (part) {
                     claim[bidx] = 0x7FFFFFFFu;
                 }
@@ -762,7 +771,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
             if (lane < stop) {
                 done = true;
             }
-            __syncthreads();
+            wave_sync();
             if (stop == 64) {
                 break;
             }
@@ -795,14 +804,14 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 if (lane == stop) {
                     done = true;
                 }
-                __syncthreads();
+                wave_sync();
             }
         }
         if (mq < nq) {
             P.acc_idx[mq] = myacc;
         }
     }
-    __syncthreads();
+    wave_sync();
     u32 num = wave_sum_u32(mynum);
 
     const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm || pp.kind == kRange);
@@ -844,11 +853,11 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (lane == 0) {
             ovs_sort::index_sort_by_size(hist, order, 30);
         }
-        __syncthreads();
+        wave_sync();
         const u32 v0 = order[0], v1 = order[1], v2 = order[2];
         u32 removed = 0;
         for (int q0 = lane; q0 < nq; q0 += 64 * U) {
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         }
         removed = wave_sum_u32(removed);
         num -= removed;
-        __syncthreads();
+        wave_sync();
     }
     if (IN_LDS && excl) {
         for (int i = lane; i < n; i += 64) {
