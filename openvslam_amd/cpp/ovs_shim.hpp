@@ -5,7 +5,8 @@
 // matrix types and only use the member names the reference's own implementation uses
 // (landmarks_, undist_keypts_, descriptors_, stereo_x_right_, scale_factors_, camera_, ...), so in
 // the reference tree they are instantiated with data::frame, data::keyframe, data::landmark and
-// cv::Mat; this file itself includes neither OpenCV nor Eigen.
+// cv::Mat; this file itself includes neither OpenCV nor Eigen.  namespace util mirrors
+// util/image_converter.h and util/stereo_rectifier.h (the image preparation in front of extract()).
 //
 // What stays on the host, exactly where the reference has it: camera reprojection (double
 // precision), landmark getters (they take mutexes), the final pointer writes.  What moves to the
@@ -52,6 +53,9 @@ struct mat_traits {
     static size_t step(const Mat& m) { return static_cast<size_t>(m.step); }
     static void create_u8(Mat& m, int rows, int cols) { m.create(rows, cols); }
     static void release(Mat& m) { m.release(); }
+    // only the image preparation (namespace util below) asks for these two
+    static int channels(const Mat& m) { return m.channels(); }
+    static int elem_size1(const Mat& m) { return static_cast<int>(m.elemSize1()); } // bytes per channel value
 };
 
 inline ovs_grid make_grid(float min_x, float min_y, float max_x, float max_y, double inv_cell_width, double inv_cell_height,
@@ -279,6 +283,106 @@ private:
 };
 
 } // namespace feature
+
+namespace util {
+
+// util/image_converter.h.  camera::color_order_t: Gray = 0, RGB = 1, BGR = 2 (camera/base.h:32-36).
+// image_converter.cc:8-39: 3- and 4-channel images become single-channel in place; other images and
+// color order Gray are left as they are.
+template <class Mat, class ColorOrder>
+void convert_to_grayscale(Mat& img, const ColorOrder in_color_order, int device = 0) {
+    typedef mat_traits<Mat> mt;
+    const int cn = mt::channels(img), order = static_cast<int>(in_color_order);
+    if ((cn != 3 && cn != 4) || order == OVS_COLOR_GRAY || mt::empty(img)) {
+        return;
+    }
+    const int w = mt::cols(img), h = mt::rows(img);
+    std::vector<uint8_t> gray(static_cast<size_t>(w) * h);
+    check(ovs_convert_to_grayscale(mt::data(img), w, h, cn, mt::step(img), order, gray.data(), static_cast<size_t>(w), device));
+    mt::create_u8(img, h, w);
+    for (int y = 0; y < h; ++y) {
+        std::memcpy(mt::data(img) + mt::step(img) * y, gray.data() + static_cast<size_t>(w) * y, static_cast<size_t>(w));
+    }
+}
+
+// image_converter.cc:45-61: CV_8UC1 or CV_16UC1 in, CV_8UC1 out, in place
+template <class Mat>
+void equalize_histogram(Mat& img, int device = 0) {
+    typedef mat_traits<Mat> mt;
+    const int w = mt::cols(img), h = mt::rows(img), bits = 8 * mt::elem_size1(img);
+    std::vector<uint8_t> out(static_cast<size_t>(w) * h);
+    check(ovs_equalize_histogram(mt::data(img), w, h, mt::step(img), bits, out.data(), static_cast<size_t>(w), device));
+    mt::create_u8(img, h, w);
+    for (int y = 0; y < h; ++y) {
+        std::memcpy(mt::data(img) + mt::step(img) * y, out.data() + static_cast<size_t>(w) * y, static_cast<size_t>(w));
+    }
+}
+
+// util/stereo_rectifier.h.  The reference's constructors build the four CV_32FC1 maps with
+// cv::initUndistortRectifyMap from the StereoRectifier.* entries of the configuration
+// (stereo_rectifier.cc:12-53); that one-time host computation stays with the caller, who passes the maps.
+class stereo_rectifier {
+public:
+    template <class MatF>
+    stereo_rectifier(const MatF& undist_map_x_l, const MatF& undist_map_y_l, const MatF& undist_map_x_r, const MatF& undist_map_y_r, int device = 0) {
+        l_ = make(undist_map_x_l, undist_map_y_l, device);
+        try {
+            r_ = make(undist_map_x_r, undist_map_y_r, device);
+        }
+        catch (...) {
+            ovs_remap_destroy(l_);
+            throw;
+        }
+    }
+    stereo_rectifier(const stereo_rectifier&) = delete;
+    stereo_rectifier& operator=(const stereo_rectifier&) = delete;
+    virtual ~stereo_rectifier() {
+        ovs_remap_destroy(l_);
+        ovs_remap_destroy(r_);
+    }
+
+    // stereo_rectifier.cc:56-60
+    template <class Mat>
+    void rectify(const Mat& in_img_l, const Mat& in_img_r, Mat& out_img_l, Mat& out_img_r) const {
+        apply(l_, wl_, hl_, in_img_l, out_img_l);
+        apply(r_, wr_, hr_, in_img_r, out_img_r);
+    }
+
+private:
+    template <class MatF>
+    ovs_remap* make(const MatF& mx, const MatF& my, int device) {
+        typedef mat_traits<MatF> mt;
+        const int w = mt::cols(mx), h = mt::rows(mx);
+        if (mt::cols(my) != w || mt::rows(my) != h || mt::elem_size1(mx) != 4 || mt::elem_size1(my) != 4) {
+            throw std::runtime_error("rectification maps must be two CV_32FC1 images of one size");
+        }
+        std::vector<float> x(static_cast<size_t>(w) * h), y(x.size());
+        for (int r = 0; r < h; ++r) {
+            std::memcpy(x.data() + static_cast<size_t>(w) * r, mt::data(mx) + mt::step(mx) * r, sizeof(float) * w);
+            std::memcpy(y.data() + static_cast<size_t>(w) * r, mt::data(my) + mt::step(my) * r, sizeof(float) * w);
+        }
+        ovs_remap* out = nullptr;
+        check(ovs_remap_create(x.data(), y.data(), w, h, device, &out));
+        (wl_ == 0 ? wl_ : wr_) = w;
+        (hl_ == 0 ? hl_ : hr_) = h;
+        return out;
+    }
+    template <class Mat>
+    static void apply(ovs_remap* r, int w, int h, const Mat& in, Mat& out) {
+        typedef mat_traits<Mat> mt;
+        std::vector<uint8_t> buf(static_cast<size_t>(w) * h);
+        check(ovs_remap_apply(r, mt::data(in), mt::cols(in), mt::rows(in), mt::step(in), buf.data(), static_cast<size_t>(w)));
+        mt::create_u8(out, h, w);
+        for (int y = 0; y < h; ++y) {
+            std::memcpy(mt::data(out) + mt::step(out) * y, buf.data() + static_cast<size_t>(w) * y, static_cast<size_t>(w));
+        }
+    }
+    ovs_remap* l_ = nullptr;
+    ovs_remap* r_ = nullptr;
+    int wl_ = 0, hl_ = 0, wr_ = 0, hr_ = 0;
+};
+
+} // namespace util
 
 namespace match {
 

@@ -66,9 +66,17 @@ struct mat_u8 {
     std::shared_ptr<std::vector<uint8_t>> store;
     void create(int r, int c) {
         store = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(r) * c);
-        data = store->data(); rows = r; cols = c; step = c;
+        data = store->data(); rows = r; cols = c; step = c; cn = 1; esz1 = 1;
     }
     void release() { store.reset(); data = nullptr; rows = cols = 0; step = 0; }
+    // multi-channel / wider element images of the image preparation
+    int cn = 1, esz1 = 1;
+    int channels() const { return cn; }
+    size_t elemSize1() const { return static_cast<size_t>(esz1); }
+    void create_raw(int r, int c, int channels_, int elem_bytes) {
+        store = std::make_shared<std::vector<uint8_t>>(static_cast<size_t>(r) * c * channels_ * elem_bytes);
+        data = store->data(); rows = r; cols = c; cn = channels_; esz1 = elem_bytes; step = static_cast<size_t>(c) * channels_ * elem_bytes;
+    }
 };
 
 struct keypoint { float x, y, size, angle, response; int octave, class_id; };
@@ -267,6 +275,30 @@ int main(int argc, char** argv) {
     std::vector<mock::landmark*> bow_matched;
     for (unsigned i = 0; i < frm[1].num_keypts_; ++i) frm[1].landmarks_[i] = all_lms[i % all_lms.size()];
     const unsigned n_bow = match::bow_tree(0.75f, true).match_keyframes(&frm[0], &frm[1], bow_matched);
+    // image preparation: BGR -> gray of a colour copy of frame 0 (equal channels stay), identity
+    // rectification, histogram stretch
+    mock::mat_u8 bgr;
+    bgr.create_raw(h, w, 3, 1);
+    for (int i = 0; i < w * h; ++i) for (int ch = 0; ch < 3; ++ch) bgr.data[3 * i + ch] = img[0].data[i];
+    util::convert_to_grayscale(bgr, OVS_COLOR_BGR);
+    const bool gray_ok = bgr.channels() == 1 && std::memcmp(bgr.data, img[0].data, static_cast<size_t>(w) * h) == 0;
+    mock::mat_u8 map_x, map_y;
+    map_x.create_raw(h, w, 1, 4);
+    map_y.create_raw(h, w, 1, 4);
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        reinterpret_cast<float*>(map_x.data)[y * w + x] = static_cast<float>(x);
+        reinterpret_cast<float*>(map_y.data)[y * w + x] = static_cast<float>(y);
+    }
+    mock::mat_u8 rect_l, rect_r;
+    {
+        util::stereo_rectifier rectifier(map_x, map_y, map_x, map_y);
+        rectifier.rectify(img[0], img[1], rect_l, rect_r);
+    }
+    const bool rect_ok = std::memcmp(rect_l.data, img[0].data, static_cast<size_t>(w) * h) == 0 && std::memcmp(rect_r.data, img[1].data, static_cast<size_t>(w) * h) == 0;
+    util::equalize_histogram(rect_l);
+    int eq_min = 255, eq_max = 0;
+    for (int i = 0; i < w * h; ++i) { eq_min = std::min<int>(eq_min, rect_l.data[i]); eq_max = std::max<int>(eq_max, rect_l.data[i]); }
+    const bool pre_ok = gray_ok && rect_ok && eq_min == 0 && eq_max == 255;
     // brute force + (stand-in) essential-matrix inlier selection
     std::vector<mock::landmark*> robust_matched;
     const unsigned n_rkf = match::robust(0.75f, true).match_frame_and_keyframe<mock::row_solver>(frm[1], &frm[0], robust_matched);
@@ -316,12 +348,12 @@ int main(int argc, char** argv) {
     for (auto& lm : lms2) replaced += lm->erased;
     for (auto& lm : lms) { replaced += lm->erased; adopted += lm->is_observed_in_keyframe(&frm[1]); }
     std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u "
-                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u\n",
+                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d\n",
                 frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow, n_rkf, n_tri, n_area, n_mutual,
-                n_detect, n_replace, replaced, adopted);
+                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0);
     const bool ok = n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100
                     && n_rkf > 50 && n_rkf <= n_bf && n_tri == tri_pairs.size() && n_tri > 50 && n_area > 50 && area_moved == n_area
                     && n_mutual == mutual_written && n_mutual > 100 && n_detect == dup_written && n_detect > 100 && n_replace == replaced
-                    && n_replace > 100 && adopted > 50;
+                    && n_replace > 100 && adopted > 50 && pre_ok;
     return ok ? 0 : 2;
 }
