@@ -204,9 +204,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames matched per step and GPU")
+    ap.add_argument("--batch", type=int, default=765, help="frames matched per step and GPU (a multiple of --streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="contiguous sub-batches of the step's batch in flight on separate HIP streams (each re-extracts one halo frame)")
+    ap.add_argument("--streams", type=int, default=3, help="contiguous sub-batches of the step's batch in flight on separate HIP streams (each re-extracts one halo frame)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -225,12 +225,16 @@ def main():
 
     n_frames = args.batch + 1
     frames = make_frames_on_device(n_frames, dev, seed=0xC0FFEE + rank)
-    pipe = Pipeline(local_rank, n_frames)
+    # The batch as `streams` contiguous sub-batches, each with its own extractor handle, buffers and
+    # stream; sub-batch k starts with the last frame of sub-batch k - 1 as its halo.  The defaults make
+    # every launch work on 255 + 1 = 256 frames: the kernels with one workgroup per (frame, level) or
+    # per frame then fill the 256 compute units without a ragged last round, and three streams keep
+    # the device busy while such a kernel of one stream runs.
+    per = args.batch // args.streams
+    if per * args.streams != args.batch:
+        raise SystemExit("--batch must be a multiple of --streams")
+    pipe = Pipeline(local_rank, per + 1)  # one sub-batch on the default stream: the per-kernel timing pass
     if args.streams > 1:
-        # the batch as `streams` contiguous sub-batches, each with its own extractor handle, buffers and
-        # stream; sub-batch k starts with the last frame of sub-batch k - 1 as its halo
-        per = args.batch // args.streams
-        assert per * args.streams == args.batch
         subs = [Pipeline(local_rank, per + 1, torch.cuda.Stream(dev)) for _ in range(args.streams)]
 
         class Multi:
@@ -283,6 +287,7 @@ def main():
         "config": {"workload": "KITTI-shaped 1241x376 mono batch, 2000 kp, 8 levels, scale 1.2, "
                                "extract + match::projection (current vs last frame, margin 20, orientation check)",
                    "frames_per_step_per_gpu": args.batch, "halo_frames_per_step": args.streams, "streams": args.streams,
+                   "frames_per_launch": per + 1,
                    "mean_keypoints_per_frame": float(counts.mean()), "mean_matches_per_frame": float(nm[1:].mean())},
     }
 
@@ -295,7 +300,7 @@ def main():
         L.ovs_timing_enable(1)
         prof_steps = 3
         for _ in range(prof_steps):
-            pipe.step(frames)
+            pipe.step(frames[:per + 1])
         torch.cuda.synchronize(dev)
         L.ovs_timing_enable(0)
         rep = _lib.timing_report()
@@ -303,7 +308,7 @@ def main():
         launches = {k: v[1] // prof_steps for k, v in rep.items()}
         dominant = max(per_step, key=per_step.get)
         bytes_key = STAGE_OF_KERNEL.get(dominant, dominant)
-        alg_bytes_per_launch = STAGE_BYTES[bytes_key] * n_frames / max(launches[dominant], 1)
+        alg_bytes_per_launch = STAGE_BYTES[bytes_key] * (per + 1) / max(launches[dominant], 1)
         avg_ms = per_step[dominant] / max(launches[dominant], 1)
         achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -314,7 +319,8 @@ def main():
                            "path_bytes_per_frame": PATH_BYTES_PER_FRAME,
                            "path_achieved_gbs": PATH_BYTES_PER_FRAME * value / world / 1e9,
                            "path_frac": PATH_BYTES_PER_FRAME * value / world / 1e9 / HBM_PEAK_GBS,
-                           "kernel_ms_per_step": per_step}
+                           "kernel_ms_per_launch_set": per_step,
+                           "timing_pass": "one sub-batch of %d frames alone on one stream" % (per + 1)}
         if world == 1 and not args.no_cpu_baseline:
             host_frames = frames[:min(n_frames, 257)].cpu().numpy()
             fps, sample, cores, single = cpu_baseline(host_frames, args.cpu_seconds)

@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1"
+BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 255 --streams 1"
 
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 echo "trace pass done"
