@@ -325,9 +325,9 @@ class stereo_rectifier {
 public:
     template <class MatF>
     stereo_rectifier(const MatF& undist_map_x_l, const MatF& undist_map_y_l, const MatF& undist_map_x_r, const MatF& undist_map_y_r, int device = 0) {
-        l_ = make(undist_map_x_l, undist_map_y_l, device);
+        l_ = make(undist_map_x_l, undist_map_y_l, device, wl_, hl_);
         try {
-            r_ = make(undist_map_x_r, undist_map_y_r, device);
+            r_ = make(undist_map_x_r, undist_map_y_r, device, wr_, hr_);
         }
         catch (...) {
             ovs_remap_destroy(l_);
@@ -350,9 +350,10 @@ public:
 
 private:
     template <class MatF>
-    ovs_remap* make(const MatF& mx, const MatF& my, int device) {
+    static ovs_remap* make(const MatF& mx, const MatF& my, int device, int& w, int& h) {
         typedef mat_traits<MatF> mt;
-        const int w = mt::cols(mx), h = mt::rows(mx);
+        w = mt::cols(mx);
+        h = mt::rows(mx);
         if (mt::cols(my) != w || mt::rows(my) != h || mt::elem_size1(mx) != 4 || mt::elem_size1(my) != 4) {
             throw std::runtime_error("rectification maps must be two CV_32FC1 images of one size");
         }
@@ -363,8 +364,6 @@ private:
         }
         ovs_remap* out = nullptr;
         check(ovs_remap_create(x.data(), y.data(), w, h, device, &out));
-        (wl_ == 0 ? wl_ : wr_) = w;
-        (hl_ == 0 ? hl_ : hr_) = h;
         return out;
     }
     template <class Mat>
