@@ -37,7 +37,7 @@ def timed(fn, steps, warmup):
 
 def stereo(args):
     dev = torch.device("cuda", 0)
-    w, h, n_kp, batch = 752, 480, 1000, 64
+    w, h, n_kp, batch = 752, 480, 1000, 128
     fxb, fx = 47.90639384423901, 435.2046959714599
     pairs = [synth.make_stereo_pair(w, h, seed=100 + i) for i in range(4)]
     left = torch.from_numpy(np.stack([pairs[i % 4][0] for i in range(batch)])).to(dev)
@@ -66,7 +66,7 @@ def stereo(args):
 
 def equirect(args):
     dev = torch.device("cuda", 0)
-    w, h, n_kp, batch = 1920, 960, 4000, 64
+    w, h, n_kp, batch = 1920, 960, 4000, 255  # + 1 halo frame = 256 frames per launch
     rects = [(0.0, 1.0, 0.0, 0.1), (0.0, 1.0, 0.84, 1.0), (0.0, 0.2, 0.7, 1.0), (0.8, 1.0, 0.7, 1.0)]
     frames = torch.from_numpy(synth.make_sequence(w, h, batch + 1, seed=77, dx=3, dy=1)).to(dev)
     ext = orb_extractor(orb_params(max_num_keypts=n_kp, mask_rects=rects))
