@@ -518,6 +518,27 @@ int ovs_remap_apply_dev(ovs_remap* r, const uint8_t* d_src, int n_frames, int sr
 int ovs_remap_apply(ovs_remap* r, const uint8_t* src, int src_width, int src_height, size_t src_stride,
                     uint8_t* dst, size_t dst_stride);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Saved maps as descriptor databases                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* The keyframe descriptors of a map written by io::map_database_io::save_message_pack
+ * (src/openvslam/io/map_database_io.cc:19-46): root["keyframes"][std::to_string(id)]["descs"] =
+ * n_keypts x 8 uint32 words of the descriptor rows (data/common.cc:71-82, data/keyframe.cc:127).
+ * Host code (no GPU needed); rows come in ascending keyframe id order and feed
+ * ovs_desc_db_upload.  A missing file or a file of another structure gives
+ * OVS_ERR_INVALID_ARGUMENT (the reference throws std::runtime_error, map_database_io.cc:60-63). */
+typedef struct ovs_map_file ovs_map_file;
+int ovs_map_open(const char* path, ovs_map_file** out);
+void ovs_map_close(ovs_map_file* m);
+int ovs_map_num_keyframes(const ovs_map_file* m);
+int64_t ovs_map_num_descriptors(const ovs_map_file* m);
+/* ids: num_keyframes entries; row_offsets: num_keyframes + 1 entries (rows of keyframe i are
+ * [row_offsets[i], row_offsets[i + 1])) */
+int ovs_map_keyframe_rows(const ovs_map_file* m, int32_t* ids, int64_t* row_offsets);
+/* descs: num_descriptors x 32 bytes */
+int ovs_map_copy_descriptors(const ovs_map_file* m, uint8_t* descs);
+
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points
  * keep their scratch memory per (host thread, device, stream), so independent batches may be in

@@ -99,6 +99,14 @@ def _declare(L):
     L.ovs_remap_destroy.restype = None
     L.ovs_remap_apply_dev.argtypes = [vp, vp, i, i, i, sz, sz, vp, sz, sz, vp]
     L.ovs_remap_apply.argtypes = [vp, A.u8p, i, i, sz, A.u8p, sz]
+    L.ovs_map_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.ovs_map_close.argtypes = [vp]
+    L.ovs_map_close.restype = None
+    L.ovs_map_num_keyframes.argtypes = [vp]
+    L.ovs_map_num_descriptors.argtypes = [vp]
+    L.ovs_map_num_descriptors.restype = C.c_int64
+    L.ovs_map_keyframe_rows.argtypes = [vp, A.i32p, C.POINTER(C.c_int64)]
+    L.ovs_map_copy_descriptors.argtypes = [vp, A.u8p]
     L.ovs_stereo_compute_batch_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, vp, i, vp]
     L.ovs_brute_force_match.argtypes = [A.u8p, A.f32p, i, A.u8p, A.f32p, A.u8p, i, C.c_float, i, A.i32p, A.u32p, i]
     bv = C.POINTER(A.BowFeatVec)
