@@ -60,12 +60,13 @@ class orb_extractor:
         h = C.c_void_p()
         check(lib().ovs_orb_create(self._abi_params.ref(), device, C.byref(h)))
         self._h = h
+        self._destroy = lib().ovs_orb_destroy  # kept on the object: module globals may be gone at interpreter exit
         self.device = device
         self._last_shape = None
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().ovs_orb_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     # ---- extract --------------------------------------------------------------------------------

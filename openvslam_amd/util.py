@@ -52,10 +52,11 @@ class remap:
         h = C.c_void_p()
         check(lib().ovs_remap_create(A.ptr(self._mx, A.f32p), A.ptr(self._my, A.f32p), self.width, self.height, device, C.byref(h)))
         self._h = h
+        self._destroy = lib().ovs_remap_destroy  # kept on the object: module globals may be gone at interpreter exit
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().ovs_remap_destroy(self._h)
+            self._destroy(self._h)
             self._h = None
 
     def apply(self, img):
