@@ -304,6 +304,17 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
                            float focal_x_baseline, float true_baseline,
                            float* d_stereo_x_right, float* d_depths, int device, void* stream);
 
+/* stereo::compute for the live path: the two pyramids are the ones the extractor handles still
+ * hold on the device after their last ovs_orb_extract (data/frame.cc:64-77 runs the two
+ * extractions and then match::stereo on their image_pyramid_), so only keypoints and descriptors
+ * travel to the device and two float arrays come back.  Host buffers, synchronous. */
+int ovs_stereo_compute_resident(ovs_orb* left, ovs_orb* right,
+                                const ovs_keypoint* keypts_left, int n_left,
+                                const ovs_keypoint* keypts_right, int n_right,
+                                const uint8_t* descs_left, const uint8_t* descs_right,
+                                float focal_x_baseline, float true_baseline,
+                                float* stereo_x_right, float* depths, int device);
+
 /* stereo::compute for a batch of pairs in one set of launches: pair p is frame p of the last
  * ovs_orb_extract_batch_dev on `left` and on `right` (both with >= n_pairs frames), keypoint /
  * descriptor / count arrays in that call's layout (n_pairs x cap, counts per frame), outputs

@@ -107,6 +107,7 @@ def _declare(L):
     L.ovs_map_num_descriptors.restype = C.c_int64
     L.ovs_map_keyframe_rows.argtypes = [vp, A.i32p, C.POINTER(C.c_int64)]
     L.ovs_map_copy_descriptors.argtypes = [vp, A.u8p]
+    L.ovs_stereo_compute_resident.argtypes = [vp, vp, A.kpp, i, A.kpp, i, A.u8p, A.u8p, C.c_float, C.c_float, A.f32p, A.f32p, i]
     L.ovs_stereo_compute_batch_dev.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, vp, i, vp]
     L.ovs_brute_force_match.argtypes = [A.u8p, A.f32p, i, A.u8p, A.f32p, A.u8p, i, C.c_float, i, A.i32p, A.u32p, i]
     bv = C.POINTER(A.BowFeatVec)

@@ -258,7 +258,7 @@ public:
         }
         return pl;
     }
-    std::vector<plane> image_pyramid_; // filled lazily by match::stereo through image_pyramid_level()
+    std::vector<plane> image_pyramid_; // sized like the reference's member; the pixels stay on the device (image_pyramid_level() copies one level)
 
     ovs_orb* handle() { return h_; }
 
@@ -1064,7 +1064,10 @@ private:
     }
 };
 
-// match/stereo.h: constructed from the two extractors' pyramids, keypoints and descriptors
+// match/stereo.h: constructed from the two extractors (whose image_pyramid_ the reference reads,
+// data/frame.cc:77), keypoints and descriptors.  The pyramids stay on the device inside the
+// extractor handles; compute() must run before either extractor extracts again, as in the
+// reference's frame constructor.
 class stereo {
 public:
     template <class KeyPoint, class Mat>
@@ -1072,14 +1075,9 @@ public:
            const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right,
            const std::vector<float>& scale_factors, const std::vector<float>& inv_scale_factors,
            const float focal_x_baseline, const float true_baseline, int device = 0)
-        : scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors), focal_x_baseline_(focal_x_baseline),
-          true_baseline_(true_baseline), device_(device) {
+        : left_(left), right_(right), scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors),
+          focal_x_baseline_(focal_x_baseline), true_baseline_(true_baseline), device_(device) {
         static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout expected");
-        const unsigned levels = left.get_num_scale_levels();
-        for (unsigned l = 0; l < levels; ++l) {
-            left_.push_back(left.image_pyramid_level(l));
-            right_.push_back(right.image_pyramid_level(l));
-        }
         kl_.resize(keypts_left.size());
         kr_.resize(keypts_right.size());
         if (!kl_.empty()) std::memcpy(kl_.data(), keypts_left.data(), kl_.size() * sizeof(ovs_keypoint));
@@ -1093,23 +1091,19 @@ public:
 
     // stereo.cc:18-113
     void compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
-        std::vector<ovs_image_view> lv(left_.size()), rv(right_.size());
-        for (size_t l = 0; l < left_.size(); ++l) {
-            lv[l].data = left_[l].pixels.data(); lv[l].width = left_[l].width; lv[l].height = left_[l].height; lv[l].stride = left_[l].width;
-            rv[l].data = right_[l].pixels.data(); rv[l].width = right_[l].width; rv[l].height = right_[l].height; rv[l].stride = right_[l].width;
-        }
         stereo_x_right.assign(kl_.size(), -1.0f);
         depths.assign(kl_.size(), -1.0f);
-        check(ovs_stereo_compute(lv.data(), rv.data(), static_cast<int>(lv.size()), kl_.data(), static_cast<int>(kl_.size()),
-                                 kr_.data(), static_cast<int>(kr_.size()), dl_.data(), dr_.data(), scale_factors_.data(),
-                                 inv_scale_factors_.data(), focal_x_baseline_, true_baseline_, stereo_x_right.data(), depths.data(), device_));
+        check(ovs_stereo_compute_resident(left_.handle(), right_.handle(), kl_.data(), static_cast<int>(kl_.size()), kr_.data(),
+                                          static_cast<int>(kr_.size()), dl_.data(), dr_.data(), focal_x_baseline_, true_baseline_,
+                                          stereo_x_right.data(), depths.data(), device_));
     }
 
 private:
-    std::vector<feature::orb_extractor::plane> left_, right_;
+    feature::orb_extractor& left_;
+    feature::orb_extractor& right_;
     std::vector<ovs_keypoint> kl_, kr_;
     std::vector<uint8_t> dl_, dr_;
-    const std::vector<float> scale_factors_, inv_scale_factors_;
+    const std::vector<float> scale_factors_, inv_scale_factors_; // kept for the signature; the handles hold the same tables
     const float focal_x_baseline_, true_baseline_;
     const int device_;
 };

@@ -592,6 +592,72 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
                          d_row_start, d_row_items, items_cap, d_corr, d_err, d_stereo_x_right, d_depths, st);
 }
 
+int ovs_stereo_compute_resident(ovs_orb* left, ovs_orb* right,
+                                const ovs_keypoint* keypts_left, int n_left, const ovs_keypoint* keypts_right, int n_right,
+                                const uint8_t* descs_left, const uint8_t* descs_right,
+                                float focal_x_baseline, float true_baseline,
+                                float* stereo_x_right, float* depths, int device) {
+    if (!left || !right || n_left < 0 || n_right < 0 || (n_left > 0 && (!keypts_left || !descs_left || !stereo_x_right || !depths))
+        || (n_right > 0 && (!keypts_right || !descs_right))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) {
+        return rc;
+    }
+    hipStream_t st = ctx->stream;
+    // keypoints, descriptors and results are staged in this thread's arena; the device entry point
+    // below takes its scratch from the arena that belongs to (device, st), a different one
+    const size_t nl = n_left, nr = n_right;
+    const int cap = std::max(std::max(n_left, n_right), 1);
+    const size_t total = al(nl * sizeof(ovs_keypoint)) + al(nr * sizeof(ovs_keypoint)) + al(nl * 32) + al(nr * 32) + al(static_cast<size_t>(cap) * 4) * 2
+                         + al(8) + al(4);
+    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    auto* d_kl = cv.take<ovs_keypoint>(nl);
+    auto* d_kr = cv.take<ovs_keypoint>(nr);
+    auto* d_dl = cv.take<uint8_t>(nl * 32);
+    auto* d_dr = cv.take<uint8_t>(nr * 32);
+    auto* d_xr = cv.take<float>(cap);
+    auto* d_depth = cv.take<float>(cap);
+    auto* d_n = cv.take<int32_t>(2);
+    auto* d_status = cv.take<int32_t>(1);
+    const int32_t counts[2] = {n_left, n_right};
+    if (nl) {
+        OVS_HIP(hipMemcpyAsync(d_kl, keypts_left, nl * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
+        OVS_HIP(hipMemcpyAsync(d_dl, descs_left, nl * 32, hipMemcpyHostToDevice, st));
+    }
+    if (nr) {
+        OVS_HIP(hipMemcpyAsync(d_kr, keypts_right, nr * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
+        OVS_HIP(hipMemcpyAsync(d_dr, descs_right, nr * 32, hipMemcpyHostToDevice, st));
+    }
+    OVS_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, st));
+    // the pyramids were produced by ovs_orb_extract, which is synchronous: they are complete
+    if ((rc = ovs_stereo_compute_batch_dev(left, right, 1, d_kl, d_dl, d_n, d_kr, d_dr, d_n + 1, cap, focal_x_baseline, true_baseline, d_xr, d_depth,
+                                           d_status, device, st)) != OVS_OK) {
+        return rc;
+    }
+    int32_t status = 0;
+    if (nl) {
+        OVS_HIP(hipMemcpyAsync(stereo_x_right, d_xr, nl * 4, hipMemcpyDeviceToHost, st));
+        OVS_HIP(hipMemcpyAsync(depths, d_depth, nl * 4, hipMemcpyDeviceToHost, st));
+    }
+    OVS_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
+    OVS_HIP(hipStreamSynchronize(st));
+    if (status != 0) {
+        return ovs::fail(status, "keypoint row, octave or patch outside of the image");
+    }
+    return OVS_OK;
+}
+
 int ovs_stereo_compute_batch_dev(ovs_orb* left, ovs_orb* right, int n_pairs,
                                  const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_counts_left,
                                  const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_counts_right, int cap,

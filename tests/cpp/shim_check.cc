@@ -299,6 +299,23 @@ int main(int argc, char** argv) {
     int eq_min = 255, eq_max = 0;
     for (int i = 0; i < w * h; ++i) { eq_min = std::min<int>(eq_min, rect_l.data[i]); eq_max = std::max<int>(eq_max, rect_l.data[i]); }
     const bool pre_ok = gray_ok && rect_ok && eq_min == 0 && eq_max == 255;
+    // stereo: frame 1 is frame 0 seen dx pixels to the left, i.e. a right camera image with disparity dx
+    feature::orb_extractor ext_r(prm);
+    std::vector<mock::keypoint> kps_r;
+    mock::mat_u8 desc_r;
+    ext.extract(img[0], no_mask, frm[0].keypts_, frm[0].descriptors_); // the left pyramid must be the last one in `ext`
+    ext_r.extract(img[1], no_mask, kps_r, desc_r);
+    std::vector<float> sxr, sdepth;
+    match::stereo(ext, ext_r, frm[0].keypts_, kps_r, frm[0].descriptors_, desc_r, ext.get_scale_factors(), ext.get_inv_scale_factors(),
+                  40.0f, 0.5f).compute(sxr, sdepth);
+    unsigned n_stereo = 0, n_stereo_ok = 0;
+    for (size_t i = 0; i < sxr.size(); ++i) {
+        if (sxr[i] >= 0) {
+            ++n_stereo;
+            n_stereo_ok += std::fabs((frm[0].keypts_[i].x - sxr[i]) - dx) < 1.0f && std::fabs(sdepth[i] - 40.0f / (frm[0].keypts_[i].x - sxr[i])) < 1e-3f;
+        }
+    }
+    const bool stereo_ok = n_stereo > 200 && n_stereo_ok * 10 > n_stereo * 9;
     // brute force + (stand-in) essential-matrix inlier selection
     std::vector<mock::landmark*> robust_matched;
     const unsigned n_rkf = match::robust(0.75f, true).match_frame_and_keyframe<mock::row_solver>(frm[1], &frm[0], robust_matched);
@@ -348,12 +365,12 @@ int main(int argc, char** argv) {
     for (auto& lm : lms2) replaced += lm->erased;
     for (auto& lm : lms) { replaced += lm->erased; adopted += lm->is_observed_in_keyframe(&frm[1]); }
     std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u "
-                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d\n",
+                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d stereo %u/%u\n",
                 frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow, n_rkf, n_tri, n_area, n_mutual,
-                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0);
+                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0, n_stereo_ok, n_stereo);
     const bool ok = n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100
                     && n_rkf > 50 && n_rkf <= n_bf && n_tri == tri_pairs.size() && n_tri > 50 && n_area > 50 && area_moved == n_area
                     && n_mutual == mutual_written && n_mutual > 100 && n_detect == dup_written && n_detect > 100 && n_replace == replaced
-                    && n_replace > 100 && adopted > 50 && pre_ok;
+                    && n_replace > 100 && adopted > 50 && pre_ok && stereo_ok;
     return ok ? 0 : 2;
 }

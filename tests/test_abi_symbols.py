@@ -50,7 +50,7 @@ def test_oracle_mirrors_the_compute_entry_points():
                              r"|desc_db_(create|destroy|upload|attach_dev)|remap_(create|destroy)|map_)")
     renamed = {"ovs_orb_extract_batch_dev": "ovo_orb_extract", "ovs_orb_pyramid_level_dev": "ovo_orb_pyramid_level",
                "ovs_orb_download_pyramid_level": "ovo_orb_pyramid_level", "ovs_orb_download_blurred_level": "ovo_orb_blurred_level",
-               "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_stereo_compute_batch_dev": "ovo_stereo_compute",
+               "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_stereo_compute_batch_dev": "ovo_stereo_compute", "ovs_stereo_compute_resident": "ovo_stereo_compute",
                "ovs_convert_to_grayscale_dev": "ovo_convert_to_grayscale", "ovs_equalize_histogram_dev": "ovo_equalize_histogram",
                "ovs_equalize_histogram_u16_dev": "ovo_equalize_histogram", "ovs_remap_apply_dev": "ovo_remap_linear",
                "ovs_remap_apply": "ovo_remap_linear",

@@ -166,6 +166,39 @@ def test_stereo_batch_equals_pair_by_pair_and_oracle():
     assert _same_float(dep[0, :len(kl)].cpu().numpy(), rdep)
 
 
+def test_stereo_resident_equals_host_pyramid_path():
+    """Live path: pyramids stay in the extractor handles after the host-buffer extract; only keypoints
+    and descriptors are sent.  Same result as the entry point that takes the pyramids from the host."""
+    w, h, n = 752, 480, 1000
+    left, right, _, _ = synth.make_stereo_pair(w, h, seed=31)
+    exts = [orb_extractor(orb_params(max_num_keypts=n), device=0) for _ in range(2)]
+    kl, dl = exts[0].extract(left)
+    kr, dr = exts[1].extract(right)
+    true_baseline = np.float32(FXB / FX)
+    xr = np.full(len(kl), 7.0, dtype=np.float32)
+    dep = np.full(len(kl), 7.0, dtype=np.float32)
+    _lib.check(_lib.lib().ovs_stereo_compute_resident(exts[0]._h, exts[1]._h, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr),
+                                                      A.ptr(dl, A.u8p), A.ptr(dr, A.u8p), np.float32(FXB), true_baseline,
+                                                      A.ptr(xr, A.f32p), A.ptr(dep, A.f32p), 0))
+    ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=n), oracle.OrbExtractor(max_num_keypts=n)
+    okl, odl = ref_l.extract(left)
+    okr, odr = ref_r.extract(right)
+    assert np.array_equal(okl.view(np.uint8), kl.view(np.uint8)) and np.array_equal(odl, dl)
+    la, keep_l = _views([ref_l.pyramid_level(i) for i in range(8)])
+    ra, keep_r = _views([ref_r.pyramid_level(i) for i in range(8)])
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    isf = oracle.scale_table("inv_scale_factors", 8, 1.2)
+    rxr = np.zeros(len(kl), dtype=np.float32)
+    rdep = np.zeros(len(kl), dtype=np.float32)
+    oracle.check(oracle.lib().ovo_stereo_compute(la, ra, 8, A.ptr(okl, A.kpp), len(okl), A.ptr(okr, A.kpp), len(okr), A.ptr(odl, A.u8p), A.ptr(odr, A.u8p),
+                                                 A.ptr(sf, A.f32p), A.ptr(isf, A.f32p), np.float32(FXB), true_baseline,
+                                                 A.ptr(rxr, A.f32p), A.ptr(rdep, A.f32p)))
+    assert _same_float(xr, rxr) and _same_float(dep, rdep)
+    assert (xr >= 0).sum() > 100
+    # no keypoints at all is fine
+    _lib.check(_lib.lib().ovs_stereo_compute_resident(exts[0]._h, exts[1]._h, None, 0, None, 0, None, None, np.float32(FXB), true_baseline, None, None, 0))
+
+
 def test_stereo_out_of_range_row_is_reported():
     img = np.zeros((64, 64), dtype=np.uint8)
     la, k1 = _views([img])
