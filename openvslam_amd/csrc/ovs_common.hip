@@ -41,6 +41,28 @@ void dev_buffer::release() {
     bytes = 0;
 }
 
+int pinned_buffer::reserve(size_t n) {
+    if (n <= bytes) {
+        return OVS_OK;
+    }
+    if (ptr) {
+        OVS_HIP(hipHostFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+    }
+    OVS_HIP(hipHostMalloc(&ptr, n, hipHostMallocDefault));
+    bytes = n;
+    return OVS_OK;
+}
+
+void pinned_buffer::release() {
+    if (ptr) {
+        (void)hipHostFree(ptr);
+    }
+    ptr = nullptr;
+    bytes = 0;
+}
+
 device_guard::device_guard(int device) {
     if (hipGetDevice(&prev) != hipSuccess) {
         prev = -1;

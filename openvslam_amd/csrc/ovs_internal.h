@@ -46,6 +46,18 @@ struct dev_buffer {
     T* as() const { return static_cast<T*>(ptr); }
 };
 
+// A growable page-locked host buffer: staging for the host-buffer entry points (copies between
+// pageable caller memory and the device go through the runtime's own small staging chunks, which
+// costs milliseconds for an image; one memcpy into pinned memory and one DMA does not).
+struct pinned_buffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n);
+    void release();
+    template <typename T>
+    T* as() const { return static_cast<T*>(ptr); }
+};
+
 // RAII device selection for entry points that take a device ordinal.
 struct device_guard {
     int prev = -1;

@@ -5,6 +5,7 @@
 
 #include "ovs_internal.h"
 
+#include <cstring>
 #include <vector>
 
 namespace ovsm {
@@ -107,6 +108,7 @@ struct thread_ctx {
     hipStream_t key = nullptr;    // caller stream this context belongs to; nullptr = internal stream
     hipStream_t stream = nullptr; // internal stream (key == nullptr only)
     ovs::dev_buffer arena;
+    ovs::pinned_buffer mirror; // page-locked image of the arena, see host_stager
 };
 
 inline thread_ctx* ctx_for(int device, hipStream_t key = nullptr) {
@@ -153,6 +155,79 @@ inline int ensure_stream(thread_ctx* c) {
     }
     return OVS_OK;
 }
+
+// The host-buffer entry points move a dozen small arrays per call.  Copied one by one from pageable
+// caller memory each costs a runtime staging step; instead they are written into a page-locked
+// mirror of the arena at the offsets of their device buffers and travel in ONE transfer covering
+// the span from the first to the last of them (bytes in between belong to buffers that kernels
+// fill later).  Results come back the same way: one transfer of the span of all requested
+// outputs, one synchronisation, then plain copies into the caller's arrays.
+struct host_stager {
+    thread_ctx* ctx = nullptr;
+    hipStream_t st = nullptr;
+    size_t up_lo = ~static_cast<size_t>(0), up_hi = 0, dn_lo = ~static_cast<size_t>(0), dn_hi = 0;
+    struct pending {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<pending> gets;
+
+    // after ctx->arena.reserve(...)
+    int init(thread_ctx* c, hipStream_t stream) {
+        ctx = c;
+        st = stream;
+        return c->mirror.reserve(c->arena.bytes);
+    }
+    size_t offset_of(const void* d) const { return static_cast<size_t>(static_cast<const uint8_t*>(d) - ctx->arena.as<uint8_t>()); }
+    void touch_up(size_t off, size_t bytes) {
+        up_lo = off < up_lo ? off : up_lo;
+        up_hi = off + bytes > up_hi ? off + bytes : up_hi;
+    }
+    void put(void* d_dst, const void* src, size_t bytes) {
+        if (bytes) {
+            const size_t off = offset_of(d_dst);
+            std::memcpy(ctx->mirror.as<uint8_t>() + off, src, bytes);
+            touch_up(off, bytes);
+        }
+    }
+    void fill(void* d_dst, int value, size_t bytes) {
+        if (bytes) {
+            const size_t off = offset_of(d_dst);
+            std::memset(ctx->mirror.as<uint8_t>() + off, value, bytes);
+            touch_up(off, bytes);
+        }
+    }
+    hipError_t upload() {
+        if (up_hi <= up_lo) {
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(ctx->arena.as<uint8_t>() + up_lo, ctx->mirror.as<uint8_t>() + up_lo, up_hi - up_lo, hipMemcpyHostToDevice, st);
+    }
+    void get(void* host_dst, const void* d_src, size_t bytes) {
+        if (bytes) {
+            const size_t off = offset_of(d_src);
+            gets.push_back(pending{host_dst, off, bytes});
+            dn_lo = off < dn_lo ? off : dn_lo;
+            dn_hi = off + bytes > dn_hi ? off + bytes : dn_hi;
+        }
+    }
+    // enqueues the transfer, waits for the stream, delivers
+    hipError_t download() {
+        hipError_t e = hipSuccess;
+        if (dn_hi > dn_lo) {
+            e = hipMemcpyAsync(ctx->mirror.as<uint8_t>() + dn_lo, ctx->arena.as<uint8_t>() + dn_lo, dn_hi - dn_lo, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) {
+            e = hipStreamSynchronize(st);
+        }
+        if (e == hipSuccess) {
+            for (const pending& g : gets) {
+                std::memcpy(g.dst, ctx->mirror.as<uint8_t>() + g.off, g.bytes);
+            }
+        }
+        return e;
+    }
+};
 
 } // namespace ovsm
 

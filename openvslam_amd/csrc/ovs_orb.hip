@@ -1844,7 +1844,8 @@ struct ovs_orb {
     int batch_cap = 0;
     ovs::dev_buffer pyr, blur, slots, cell_counts, cand, lvl_xy, lvl_resp, lvl_count;
     // staging for the single-frame host entry point
-    ovs::dev_buffer st_img, st_mask, st_kps, st_desc, st_count;
+    ovs::dev_buffer st_img, st_mask, st_out;  // st_out: count (256 B), keypoints, descriptors
+    ovs::pinned_buffer pin_in, pin_out;
     hipStream_t own_stream = nullptr;
 
     // state of the last extraction (for the pyramid accessors)
@@ -2205,9 +2206,11 @@ void ovs_orb_destroy(ovs_orb* h) {
     }
     ovs::device_guard guard(h->device);
     for (ovs::dev_buffer* b : {&h->tabs, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand,
-                               &h->lvl_xy, &h->lvl_resp, &h->lvl_count, &h->st_img, &h->st_mask, &h->st_kps, &h->st_desc, &h->st_count}) {
+                               &h->lvl_xy, &h->lvl_resp, &h->lvl_count, &h->st_img, &h->st_mask, &h->st_out}) {
         b->release();
     }
+    h->pin_in.release();
+    h->pin_out.release();
     if (h->own_stream) {
         (void)hipStreamDestroy(h->own_stream);
     }
@@ -2398,27 +2401,49 @@ int ovs_orb_extract(ovs_orb* h, const uint8_t* img, int width, int height, size_
     if (dcap < 0) {
         return dcap;
     }
-    const size_t pitch = (static_cast<size_t>(width) + 63) & ~static_cast<size_t>(63);
-    if ((rc = h->st_img.reserve(pitch * height)) != OVS_OK) return rc;
-    if ((rc = h->st_kps.reserve(static_cast<size_t>(dcap) * sizeof(ovs_keypoint))) != OVS_OK) return rc;
-    if ((rc = h->st_desc.reserve(static_cast<size_t>(dcap) * 32)) != OVS_OK) return rc;
-    if ((rc = h->st_count.reserve(sizeof(int))) != OVS_OK) return rc;
-    OVS_HIP(hipMemcpy2DAsync(h->st_img.ptr, pitch, img, stride, width, height, hipMemcpyHostToDevice, h->own_stream));
+    // Image (and mask) rows are packed into page-locked staging memory and sent with one DMA each; the
+    // device copy keeps the packed layout (row pitch = width: level 0 may have any pitch).
+    const size_t w = static_cast<size_t>(width), img_bytes = w * height;
+    const size_t kp_bytes = static_cast<size_t>(dcap) * sizeof(ovs_keypoint), desc_bytes = static_cast<size_t>(dcap) * 32;
+    if ((rc = h->st_img.reserve(img_bytes + 256)) != OVS_OK) return rc;
+    if ((rc = h->st_out.reserve(256 + kp_bytes + desc_bytes)) != OVS_OK) return rc;
+    if ((rc = h->pin_in.reserve((mask ? 2 : 1) * img_bytes)) != OVS_OK) return rc;
+    if ((rc = h->pin_out.reserve(256 + kp_bytes + desc_bytes)) != OVS_OK) return rc;
+    auto pack = [&](uint8_t* dst, const uint8_t* src, size_t src_stride) {
+        if (src_stride == w) {
+            std::memcpy(dst, src, img_bytes);
+        }
+        else {
+            for (int y = 0; y < height; ++y) {
+                std::memcpy(dst + w * y, src + src_stride * y, w);
+            }
+        }
+    };
+    pack(h->pin_in.as<uint8_t>(), img, stride);
+    OVS_HIP(hipMemcpyAsync(h->st_img.ptr, h->pin_in.ptr, img_bytes, hipMemcpyHostToDevice, h->own_stream));
     const uint8_t* d_mask = nullptr;
     if (mask) {
-        if ((rc = h->st_mask.reserve(pitch * height)) != OVS_OK) return rc;
-        OVS_HIP(hipMemcpy2DAsync(h->st_mask.ptr, pitch, mask, mask_stride, width, height, hipMemcpyHostToDevice, h->own_stream));
+        if ((rc = h->st_mask.reserve(img_bytes + 256)) != OVS_OK) return rc;
+        pack(h->pin_in.as<uint8_t>() + img_bytes, mask, mask_stride);
+        OVS_HIP(hipMemcpyAsync(h->st_mask.ptr, h->pin_in.as<uint8_t>() + img_bytes, img_bytes, hipMemcpyHostToDevice, h->own_stream));
         d_mask = h->st_mask.as<uint8_t>();
     }
-    rc = ovs_orb_extract_batch_dev(h, h->st_img.as<uint8_t>(), 1, width, height, pitch, pitch * height,
-                                   d_mask, pitch, h->st_kps.as<ovs_keypoint>(), h->st_desc.as<uint8_t>(),
-                                   h->st_count.as<int32_t>(), dcap, h->own_stream);
+    uint8_t* d_out = h->st_out.as<uint8_t>();
+    auto* d_count = reinterpret_cast<int32_t*>(d_out);
+    auto* d_kps = reinterpret_cast<ovs_keypoint*>(d_out + 256);
+    uint8_t* d_desc = d_out + 256 + kp_bytes;
+    rc = ovs_orb_extract_batch_dev(h, h->st_img.as<uint8_t>(), 1, width, height, w, img_bytes, d_mask, w, d_kps, d_desc, d_count, dcap, h->own_stream);
     if (rc != OVS_OK) {
         return rc;
     }
-    int count = 0;
-    OVS_HIP(hipMemcpyAsync(&count, h->st_count.ptr, sizeof(int), hipMemcpyDeviceToHost, h->own_stream));
+    // One round trip for the usual case: the count and as many records as a full quota plus a margin
+    // come back together; a frame with more keypoints fetches the remainder afterwards.
+    uint8_t* p_out = h->pin_out.as<uint8_t>();
+    const size_t guess = std::min<size_t>(static_cast<size_t>(dcap), static_cast<size_t>(h->max_num_keypts) + h->max_num_keypts / 4 + 64);
+    OVS_HIP(hipMemcpyAsync(p_out, d_out, 256 + guess * sizeof(ovs_keypoint), hipMemcpyDeviceToHost, h->own_stream));
+    OVS_HIP(hipMemcpyAsync(p_out + 256 + kp_bytes, d_desc, guess * 32, hipMemcpyDeviceToHost, h->own_stream));
     OVS_HIP(hipStreamSynchronize(h->own_stream));
+    const int count = *reinterpret_cast<const int32_t*>(p_out);
     if (count < 0) {
         return ovs::fail(OVS_ERR_CAPACITY, "internal keypoint capacity exceeded");
     }
@@ -2426,9 +2451,15 @@ int ovs_orb_extract(ovs_orb* h, const uint8_t* img, int width, int height, size_
     if (count > cap) {
         return ovs::fail(OVS_ERR_CAPACITY, "keypoint buffer too small");
     }
+    if (static_cast<size_t>(count) > guess) {
+        const size_t rest = static_cast<size_t>(count) - guess;
+        OVS_HIP(hipMemcpyAsync(p_out + 256 + guess * sizeof(ovs_keypoint), d_kps + guess, rest * sizeof(ovs_keypoint), hipMemcpyDeviceToHost, h->own_stream));
+        OVS_HIP(hipMemcpyAsync(p_out + 256 + kp_bytes + guess * 32, d_desc + guess * 32, rest * 32, hipMemcpyDeviceToHost, h->own_stream));
+        OVS_HIP(hipStreamSynchronize(h->own_stream));
+    }
     if (count > 0) {
-        OVS_HIP(hipMemcpy(kps, h->st_kps.ptr, static_cast<size_t>(count) * sizeof(ovs_keypoint), hipMemcpyDeviceToHost));
-        OVS_HIP(hipMemcpy(desc, h->st_desc.ptr, static_cast<size_t>(count) * 32, hipMemcpyDeviceToHost));
+        std::memcpy(kps, p_out + 256, static_cast<size_t>(count) * sizeof(ovs_keypoint));
+        std::memcpy(desc, p_out + 256 + kp_bytes, static_cast<size_t>(count) * 32);
     }
     return OVS_OK;
 }

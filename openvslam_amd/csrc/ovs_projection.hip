@@ -597,13 +597,15 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
 // change its outcome is handled alone with a full rescan of its window.
 // IN_LDS: the per-keypoint `matched` and `claim` arrays fit in LDS next to the bitmap; otherwise
 // they stay in global memory and queries are retired one per round.
-// The resolve kernel is one wavefront per workgroup: LDS traffic of a single wave is processed in
-// order, so a point where all lanes must see each other's LDS writes needs the LDS counter drained
-// and the compiler kept from moving accesses across it, not s_barrier (whose preceding full wait
-// would also stall on the global loads that are deliberately left in flight).
+// The resolve kernel is one wavefront per workgroup.  The LDS unit executes the instructions of one
+// wave in the order they were issued, so a read that follows a write of another lane in program
+// order sees it: a point where all lanes must see each other's LDS writes only has to keep the
+// compiler from moving accesses across it.  No s_barrier (whose preceding full wait would also
+// stall on the global loads that are deliberately left in flight) and no counter drain.
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <bool IN_LDS, bool FUSE>
@@ -680,26 +682,27 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         fetch(mq + 64);
         int myacc = -1;
         while (true) {
+            // best and second best listed candidate that no earlier query has claimed: the claim bits of
+            // all listed candidates are fetched together (one LDS round trip), the selection itself
+            // is branch free
             u64 best = kNoKey, second = kNoKey;
             int found = 0;
             if (!done) {
+                u32 bw[kTopK];
+#pragma unroll
+                for (int k = 0; k < kTopK; ++k) {
+                    const u32 idx = key_idx(mykeys[k]);
+                    bw[k] = (excl && mykeys[k] != kNoKey) ? blocked[idx >> 5] >> (idx & 31) : 0u;
+                }
 #pragma unroll
                 for (int k = 0; k < kTopK; ++k) {
                     const u64 key = mykeys[k];
-                    if (key != kNoKey && found < 2) {
-                        const u32 idx = key_idx(key);
-                        const bool b = excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u);
-                        if (!b) {
-                            if (found == 0) {
-                                best = key;
-                            }
-                            else {
-                                second = key;
-                            }
-                            ++found;
-                        }
-                    }
+                    const bool avail = key != kNoKey && !(bw[k] & 1u);
+                    second = (avail && found == 1) ? key : second;
+                    best = (avail && found == 0) ? key : best;
+                    found += avail ? 1 : 0;
                 }
+                found = min(found, 2);
             }
             // A rescan can only matter if an unlisted candidate (whose distance is at least the last
             // listed one) could still be accepted or could change the ratio test.
@@ -1087,10 +1090,6 @@ int validate_frame(const ovs_frame_view* f) {
     return OVS_OK;
 }
 
-// Uploads a host frame view and builds its grid on the device.
-struct uploaded_frame {
-    frame_dev dev;
-};
 
 size_t frame_bytes(const ovs_frame_view* f) {
     const size_t n = f->num_keypts, L = f->num_scale_levels;
@@ -1098,7 +1097,14 @@ size_t frame_bytes(const ovs_frame_view* f) {
     return al(n * sizeof(ovs_keypoint)) + al(n * 32) + al(n * 4) + al(L * 4) + al((ncell + 1) * 4) + al(n * 4) + al(n * 16) + al(n * 32);
 }
 
-int upload_frame(const ovs_frame_view* f, carver& cv, hipStream_t st, frame_dev& out) {
+// Carves the device buffers of a host frame view and stages the caller's arrays for the upload.
+struct staged_frame {
+    frame_dev dev;
+    u32* d_items = nullptr;
+};
+
+void stage_frame(const ovs_frame_view* f, carver& cv, host_stager& hs, staged_frame& sf_out) {
+    frame_dev& out = sf_out.dev;
     const size_t n = f->num_keypts, L = f->num_scale_levels;
     const size_t ncell = static_cast<size_t>(f->grid.num_cols) * f->grid.num_rows;
     auto* d_kps = cv.take<ovs_keypoint>(n);
@@ -1109,14 +1115,12 @@ int upload_frame(const ovs_frame_view* f, carver& cv, hipStream_t st, frame_dev&
     auto* d_items = cv.take<u32>(n);
     auto* d_entry = cv.take<uint4>(n);
     auto* d_gdesc = cv.take<uint4>(2 * n);
-    if (n) {
-        OVS_HIP(hipMemcpyAsync(d_kps, f->undist_keypts, n * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
-        OVS_HIP(hipMemcpyAsync(d_desc, f->descriptors, n * 32, hipMemcpyHostToDevice, st));
-        if (f->stereo_x_right) {
-            OVS_HIP(hipMemcpyAsync(d_sxr, f->stereo_x_right, n * 4, hipMemcpyHostToDevice, st));
-        }
+    hs.put(d_kps, f->undist_keypts, n * sizeof(ovs_keypoint));
+    hs.put(d_desc, f->descriptors, n * 32);
+    if (f->stereo_x_right) {
+        hs.put(d_sxr, f->stereo_x_right, n * 4);
     }
-    OVS_HIP(hipMemcpyAsync(d_sf, f->scale_factors, L * 4, hipMemcpyHostToDevice, st));
+    hs.put(d_sf, f->scale_factors, L * 4);
     out.n = static_cast<int>(n);
     out.kps = d_kps;
     out.desc = d_desc;
@@ -1127,10 +1131,16 @@ int upload_frame(const ovs_frame_view* f, carver& cv, hipStream_t st, frame_dev&
     out.cell_start = d_cell_start;
     out.g_entry = d_entry;
     out.g_desc = d_gdesc;
-    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(1), dim3(256), grid_lds_bytes(f->grid), st,
-               d_kps, d_desc, static_cast<const int*>(nullptr), static_cast<int>(n), static_cast<int>(std::max<size_t>(n, 1)), f->grid,
-               d_cell_start, d_items, d_entry, d_gdesc);
-    return OVS_OK;
+    out.inv_level_sigma_sq = nullptr;
+    sf_out.d_items = d_items;
+}
+
+// Builds the grid of a staged frame (after the stager's upload has been enqueued on `st`).
+void launch_grid_build(const staged_frame& sf, hipStream_t st) {
+    const frame_dev& d = sf.dev;
+    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(1), dim3(256), grid_lds_bytes(d.grid), st,
+               d.kps, d.desc, static_cast<const int*>(nullptr), d.n, std::max(d.n, 1), d.grid,
+               const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
 }
 
 // Runs one projection-matching problem given host views.
@@ -1166,18 +1176,15 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     cv.base = ctx->arena.as<uint8_t>();
     hipStream_t st = ctx->stream;
 
-    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        if (!bytes) {
-            return hipSuccess;
-        }
-        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-    };
-
-    proj_problem P;
-    std::memset(&P, 0, sizeof(P));
-    if ((rc = upload_frame(frm, cv, st, P.frm)) != OVS_OK) {
+    host_stager hs;
+    if ((rc = hs.init(ctx, st)) != OVS_OK) {
         return rc;
     }
+    proj_problem P;
+    std::memset(&P, 0, sizeof(P));
+    staged_frame sfrm;
+    stage_frame(frm, cv, hs, sfrm);
+    P.frm = sfrm.dev;
     auto* d_occ = cv.take<uint8_t>(n);
     auto* d_rxy = cv.take<float>(nq * 2);
     auto* d_xr = cv.take<float>(nq);
@@ -1186,45 +1193,43 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     auto* d_qdesc = cv.take<uint8_t>(nq * 32);
     auto* d_valid = cv.take<uint8_t>(nq);
     auto* d_hasobs = cv.take<uint8_t>(nq);
-    auto* d_lists = cv.take<u64>(nq * kTopK);
-    auto* d_totals = cv.take<u32>(nq);
+    auto* d_rxy_d = cv.take<double>(nq * 2);
+    auto* d_isig = cv.take<float>(static_cast<size_t>(frm->num_scale_levels));
+    auto* d_prob = cv.take<proj_problem>(1);
+    // results (one span for the way back) and kernel-to-kernel buffers
     auto* d_acc = cv.take<int>(nq);
     auto* d_matched = cv.take<int>(n);
     auto* d_num = cv.take<u32>(1);
     auto* d_err = cv.take<int>(1);
-    auto* d_prob = cv.take<proj_problem>(1);
-    auto* d_rxy_d = cv.take<double>(nq * 2);
-    auto* d_isig = cv.take<float>(static_cast<size_t>(frm->num_scale_levels));
+    auto* d_lists = cv.take<u64>(nq * kTopK);
+    auto* d_totals = cv.take<u32>(nq);
     if (reproj_xy_d) {
-        OVS_HIP(up(d_rxy_d, reproj_xy_d, nq * 16));
+        hs.put(d_rxy_d, reproj_xy_d, nq * 16);
         P.q.reproj_xy_d = d_rxy_d;
     }
     if (inv_level_sigma_sq) {
-        OVS_HIP(up(d_isig, inv_level_sigma_sq, static_cast<size_t>(frm->num_scale_levels) * 4));
+        hs.put(d_isig, inv_level_sigma_sq, static_cast<size_t>(frm->num_scale_levels) * 4);
         P.frm.inv_level_sigma_sq = d_isig;
     }
-
     if (occupied) {
-        OVS_HIP(up(d_occ, occupied, n));
+        hs.put(d_occ, occupied, n);
     }
-    OVS_HIP(up(d_rxy, q->reproj_xy, nq * 8));
+    hs.put(d_rxy, q->reproj_xy, nq * 8);
     if (q->x_right) {
-        OVS_HIP(up(d_xr, q->x_right, nq * 4));
+        hs.put(d_xr, q->x_right, nq * 4);
     }
-    OVS_HIP(up(d_sl, q->scale_level, nq * 4));
+    hs.put(d_sl, q->scale_level, nq * 4);
     if (q->angle) {
-        OVS_HIP(up(d_ang, q->angle, nq * 4));
+        hs.put(d_ang, q->angle, nq * 4);
     }
-    OVS_HIP(up(d_qdesc, q->desc, nq * 32));
-    OVS_HIP(up(d_valid, q->valid, nq));
+    hs.put(d_qdesc, q->desc, nq * 32);
+    hs.put(d_valid, q->valid, nq);
     if (q->has_observation) {
-        OVS_HIP(up(d_hasobs, q->has_observation, nq));
+        hs.put(d_hasobs, q->has_observation, nq);
     }
-    OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
-    OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
-    if (nq) {
-        OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
-    }
+    hs.fill(d_acc, 0xFF, nq * 4);
+    hs.fill(d_num, 0, 4);
+    hs.fill(d_err, 0, 4);
 
     P.q.n = static_cast<int>(nq);
     P.q.reproj_xy = d_rxy;
@@ -1241,8 +1246,10 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     P.num_matches = d_num;
     P.acc_idx = d_acc;
     P.err = d_err;
-    OVS_HIP(up(d_prob, &P, sizeof(P)));
+    hs.put(d_prob, &P, sizeof(P));
+    OVS_HIP(hs.upload());
 
+    launch_grid_build(sfrm, st);
     if (nq) {
         constexpr int QPB = 256 / kGroup;
         launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
@@ -1254,15 +1261,15 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
 
     int err = 0;
     uint32_t num = 0;
-    if (matched_out && n) {
-        OVS_HIP(hipMemcpyAsync(matched_out, d_matched, n * 4, hipMemcpyDeviceToHost, st));
+    if (matched_out) {
+        hs.get(matched_out, d_matched, n * 4);
     }
-    if (best_of_query_out && nq) {
-        OVS_HIP(hipMemcpyAsync(best_of_query_out, d_acc, nq * 4, hipMemcpyDeviceToHost, st));
+    if (best_of_query_out) {
+        hs.get(best_of_query_out, d_acc, nq * 4);
     }
-    OVS_HIP(hipMemcpyAsync(&num, d_num, 4, hipMemcpyDeviceToHost, st));
-    OVS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
-    OVS_HIP(hipStreamSynchronize(st));
+    hs.get(&num, d_num, 4);
+    hs.get(&err, d_err, 4);
+    OVS_HIP(hs.download());
     if (err != 0) {
         return ovs::fail(err, "scale level or rotation bin out of range");
     }
@@ -1312,56 +1319,52 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
     carver cv;
     cv.base = ctx->arena.as<uint8_t>();
     hipStream_t st = ctx->stream;
-    auto up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-        if (!bytes) {
-            return hipSuccess;
-        }
-        return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-    };
+    host_stager hs;
+    if ((rc = hs.init(ctx, st)) != OVS_OK) {
+        return rc;
+    }
     // candidate keypoints only carry the angle (read by the rotation check)
     std::vector<ovs_keypoint> kps(n);
     for (size_t i = 0; i < n; ++i) {
         kps[i] = ovs_keypoint{0.f, 0.f, 0.f, rp.cand_angles ? rp.cand_angles[i] : 0.f, 0.f, 0, -1};
     }
-    std::vector<uint8_t> valid(nq, 1);
 
     auto* d_kps = cv.take<ovs_keypoint>(n);
     auto* d_desc = cv.take<uint8_t>(n * 32);
     auto* d_occ = cv.take<uint8_t>(n);
     auto* d_eidx = cv.take<u32>(ne);
-    auto* d_entry = cv.take<uint4>(ne);
-    auto* d_gdesc = cv.take<uint4>(2 * ne);
     auto* d_qdesc = cv.take<uint8_t>(nq * 32);
     auto* d_ang = cv.take<float>(nq);
     auto* d_lo = cv.take<u32>(nq);
     auto* d_hi = cv.take<u32>(nq);
-    auto* d_totals = cv.take<u32>(nq);
-    auto* d_acc = cv.take<int>(nq);
     auto* d_valid = cv.take<uint8_t>(nq);
-    auto* d_lists = cv.take<u64>(nq * kTopK);
+    auto* d_prob = cv.take<proj_problem>(1);
+    // results (one span for the way back) and kernel-to-kernel buffers
+    auto* d_acc = cv.take<int>(nq);
     auto* d_matched = cv.take<int>(n);
     auto* d_num = cv.take<u32>(1);
     auto* d_err = cv.take<int>(1);
-    auto* d_prob = cv.take<proj_problem>(1);
+    auto* d_totals = cv.take<u32>(nq);
+    auto* d_lists = cv.take<u64>(nq * kTopK);
+    auto* d_entry = cv.take<uint4>(ne);
+    auto* d_gdesc = cv.take<uint4>(2 * ne);
 
-    OVS_HIP(up(d_kps, kps.data(), n * sizeof(ovs_keypoint)));
-    OVS_HIP(up(d_desc, rp.cand_descs, n * 32));
+    hs.put(d_kps, kps.data(), n * sizeof(ovs_keypoint));
+    hs.put(d_desc, rp.cand_descs, n * 32);
     if (rp.cand_occupied) {
-        OVS_HIP(up(d_occ, rp.cand_occupied, n));
+        hs.put(d_occ, rp.cand_occupied, n);
     }
-    OVS_HIP(up(d_eidx, rp.entry_idx, ne * 4));
-    OVS_HIP(up(d_qdesc, rp.q_descs, nq * 32));
+    hs.put(d_eidx, rp.entry_idx, ne * 4);
+    hs.put(d_qdesc, rp.q_descs, nq * 32);
     if (rp.q_angles) {
-        OVS_HIP(up(d_ang, rp.q_angles, nq * 4));
+        hs.put(d_ang, rp.q_angles, nq * 4);
     }
-    OVS_HIP(up(d_lo, rp.q_lo, nq * 4));
-    OVS_HIP(up(d_hi, rp.q_hi, nq * 4));
-    OVS_HIP(up(d_valid, valid.data(), nq));
-    OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
-    OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
-    if (nq) {
-        OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
-    }
+    hs.put(d_lo, rp.q_lo, nq * 4);
+    hs.put(d_hi, rp.q_hi, nq * 4);
+    hs.fill(d_valid, 1, nq);
+    hs.fill(d_acc, 0xFF, nq * 4);
+    hs.fill(d_num, 0, 4);
+    hs.fill(d_err, 0, 4);
 
     proj_problem P;
     std::memset(&P, 0, sizeof(P));
@@ -1385,7 +1388,8 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
     P.num_matches = d_num;
     P.acc_idx = d_acc;
     P.err = d_err;
-    OVS_HIP(up(d_prob, &P, sizeof(P)));
+    hs.put(d_prob, &P, sizeof(P));
+    OVS_HIP(hs.upload());
 
     proj_params pp{kRange, 0.0f, OVS_DIR_NONE, 0, rp.lowe, kThrLow, rp.check_orientation, rp.angle_sign, rp.per_query_output};
     if (ne) {
@@ -1401,15 +1405,15 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
     OVS_HIP(hipGetLastError());
     int err = 0;
     uint32_t num = 0;
-    if (matched_out && n) {
-        OVS_HIP(hipMemcpyAsync(matched_out, d_matched, n * 4, hipMemcpyDeviceToHost, st));
+    if (matched_out) {
+        hs.get(matched_out, d_matched, n * 4);
     }
-    if (acc_out && nq) {
-        OVS_HIP(hipMemcpyAsync(acc_out, d_acc, nq * 4, hipMemcpyDeviceToHost, st));
+    if (acc_out) {
+        hs.get(acc_out, d_acc, nq * 4);
     }
-    OVS_HIP(hipMemcpyAsync(&num, d_num, 4, hipMemcpyDeviceToHost, st));
-    OVS_HIP(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
-    OVS_HIP(hipStreamSynchronize(st));
+    hs.get(&num, d_num, 4);
+    hs.get(&err, d_err, 4);
+    OVS_HIP(hs.download());
     if (err != 0) {
         return ovs::fail(err, "rotation bin out of range");
     }
@@ -1513,10 +1517,13 @@ int ovs_get_keypoints_in_cell(const ovs_frame_view* frm, int n_queries,
     carver cv;
     cv.base = ctx->arena.as<uint8_t>();
     hipStream_t st = ctx->stream;
-    frame_dev fd;
-    if ((rc = upload_frame(frm, cv, st, fd)) != OVS_OK) {
+    host_stager hs;
+    if ((rc = hs.init(ctx, st)) != OVS_OK) {
         return rc;
     }
+    staged_frame sfrm;
+    stage_frame(frm, cv, hs, sfrm);
+    const frame_dev& fd = sfrm.dev;
     auto* d_xy = cv.take<float>(nq * 2);
     auto* d_m = cv.take<float>(nq);
     auto* d_lo = cv.take<int>(nq);
@@ -1524,14 +1531,16 @@ int ovs_get_keypoints_in_cell(const ovs_frame_view* frm, int n_queries,
     auto* d_cnt = cv.take<u32>(nq);
     auto* d_off = cv.take<u32>(nq);
     auto* d_idx = cv.take<u32>(static_cast<size_t>(cap) + 1);
-    OVS_HIP(hipMemcpyAsync(d_xy, ref_xy, nq * 8, hipMemcpyHostToDevice, st));
-    OVS_HIP(hipMemcpyAsync(d_m, margin, nq * 4, hipMemcpyHostToDevice, st));
+    hs.put(d_xy, ref_xy, nq * 8);
+    hs.put(d_m, margin, nq * 4);
     if (min_level) {
-        OVS_HIP(hipMemcpyAsync(d_lo, min_level, nq * 4, hipMemcpyHostToDevice, st));
+        hs.put(d_lo, min_level, nq * 4);
     }
     if (max_level) {
-        OVS_HIP(hipMemcpyAsync(d_hi, max_level, nq * 4, hipMemcpyHostToDevice, st));
+        hs.put(d_hi, max_level, nq * 4);
     }
+    OVS_HIP(hs.upload());
+    launch_grid_build(sfrm, st);
     OVS_LAUNCH("k_window_list", k_window_list, dim3((n_queries + 3) / 4), dim3(256), 0, st, fd, n_queries, d_xy, d_m,
                min_level ? d_lo : nullptr, max_level ? d_hi : nullptr, 1, d_cnt, static_cast<const u32*>(nullptr), static_cast<u32*>(nullptr));
     std::vector<u32> counts(nq);

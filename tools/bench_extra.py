@@ -5,6 +5,7 @@ path at their full sizes, inputs resident in HBM, one JSON line each.
   stereo   752x480 pair, 1000 keypoints per eye: 2 x extract + match::stereo        (pairs/s)
   equirect 1920x960 frames, 4000 keypoints, rectangle masks: extract + match        (frames/s)
   knn      2000 queries against one shard of 1250 keyframes x 2000 descriptors      (distances/s)
+  live     one frame at a time through the host-buffer entry points                  (ms per frame)
   pre      BGR -> gray, rectification remap, histogram stretch on 256 raw 1241x376 frames (frames/s)
 """
 import argparse
@@ -150,13 +151,51 @@ def pre(args):
             "ms_per_step": total_ms, "stages": out}
 
 
+def live(args):
+    """The live path: one frame at a time through the host-buffer entry points (image up, keypoints and
+    descriptors down, synchronous), as the reference's tracking thread calls extract()."""
+    w, h = 1241, 376
+    frames = synth.make_sequence(w, h, 8, seed=5, dx=3, dy=1)
+    ext = orb_extractor(orb_params(max_num_keypts=2000))
+    for f in frames[:3]:
+        ext.extract(f)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(args.steps * 4):
+        for f in frames:
+            ext.extract(f)
+            n += 1
+    mono_ms = (time.perf_counter() - t0) / n * 1e3
+    sw, sh = 752, 480
+    left, right = synth.make_stereo_pair(sw, sh, seed=100)[:2]
+    el, er = orb_extractor(orb_params(max_num_keypts=1000)), orb_extractor(orb_params(max_num_keypts=1000))
+    L = _lib.lib()
+    fxb, fx = 47.90639384423901, 435.2046959714599
+
+    def stereo_frame():
+        kl, dl = el.extract(left)
+        kr, dr = er.extract(right)
+        xr = np.empty(len(kl), np.float32)
+        dep = np.empty(len(kl), np.float32)
+        _lib.check(L.ovs_stereo_compute_resident(el._h, er._h, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr), A.ptr(dl, A.u8p), A.ptr(dr, A.u8p),
+                                                 np.float32(fxb), np.float32(fxb / fx), A.ptr(xr, A.f32p), A.ptr(dep, A.f32p), 0))
+    for _ in range(3):
+        stereo_frame()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * 10):
+        stereo_frame()
+    stereo_ms = (time.perf_counter() - t0) / (args.steps * 10) * 1e3
+    return {"metric": "live single-frame latency, host buffers in and out", "value": 1e3 / mono_ms, "unit": "frames/s",
+            "mono_1241x376_2000kp_ms_per_frame": mono_ms, "stereo_752x480_1000kp_ms_per_pair": stereo_ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "all"])
+    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "live", "all"])
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    for name in (["stereo", "equirect", "knn", "pre"] if args.workload == "all" else [args.workload]):
+    for name in (["stereo", "equirect", "knn", "pre", "live"] if args.workload == "all" else [args.workload]):
         print(json.dumps(dict(workload=name, **globals()[name](args))))
 
 
