@@ -229,6 +229,30 @@ struct host_stager {
     }
 };
 
+// Image rows between pageable caller memory and a packed device buffer of the arena, through the
+// page-locked mirror (one contiguous transfer instead of a strided copy from pageable memory).
+inline hipError_t image_up(thread_ctx* ctx, hipStream_t st, void* d_dst, const void* src, size_t src_stride, size_t row_bytes, int rows) {
+    uint8_t* pin = ctx->mirror.as<uint8_t>() + (static_cast<uint8_t*>(d_dst) - ctx->arena.as<uint8_t>());
+    for (int y = 0; y < rows; ++y) {
+        std::memcpy(pin + row_bytes * y, static_cast<const uint8_t*>(src) + src_stride * y, row_bytes);
+    }
+    return hipMemcpyAsync(d_dst, pin, row_bytes * rows, hipMemcpyHostToDevice, st);
+}
+// enqueues the transfer and waits for the stream before the rows are delivered
+inline hipError_t image_down(thread_ctx* ctx, hipStream_t st, void* dst, size_t dst_stride, const void* d_src, size_t row_bytes, int rows) {
+    uint8_t* pin = ctx->mirror.as<uint8_t>() + (static_cast<const uint8_t*>(d_src) - ctx->arena.as<uint8_t>());
+    hipError_t e = hipMemcpyAsync(pin, d_src, row_bytes * rows, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) {
+        e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess) {
+        for (int y = 0; y < rows; ++y) {
+            std::memcpy(static_cast<uint8_t*>(dst) + dst_stride * y, pin + row_bytes * y, row_bytes);
+        }
+    }
+    return e;
+}
+
 } // namespace ovsm
 
 #endif

@@ -394,12 +394,14 @@ int ovs_convert_to_grayscale(const uint8_t* src, int width, int height, int chan
     cv.base = ctx->arena.as<uint8_t>();
     auto* d_in = cv.take<uint8_t>(in_bytes);
     auto* d_out = cv.take<uint8_t>(out_bytes);
-    OVS_HIP(hipMemcpy2DAsync(d_in, in_row, src, src_stride, in_row, height, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->mirror.reserve(ctx->arena.bytes)) != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(image_up(ctx, ctx->stream, d_in, src, src_stride, in_row, height));
     if ((rc = ovs_convert_to_grayscale_dev(d_in, 1, width, height, channels, in_row, in_bytes, color_order, d_out, width, out_bytes, device, ctx->stream)) != OVS_OK) {
         return rc;
     }
-    OVS_HIP(hipMemcpy2DAsync(dst, dst_stride, d_out, width, width, height, hipMemcpyDeviceToHost, ctx->stream));
-    OVS_HIP(hipStreamSynchronize(ctx->stream));
+    OVS_HIP(image_down(ctx, ctx->stream, dst, dst_stride, d_out, width, height));
     return OVS_OK;
 }
 
@@ -490,7 +492,10 @@ int ovs_equalize_histogram(const void* src, int width, int height, size_t src_st
     auto* d_in = cv.take<uint8_t>(in_bytes);
     auto* d_out = cv.take<uint8_t>(out_bytes);
     auto* d_flag = cv.take<int32_t>(1);
-    OVS_HIP(hipMemcpy2DAsync(d_in, in_row, src, src_stride, in_row, height, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->mirror.reserve(ctx->arena.bytes)) != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(image_up(ctx, ctx->stream, d_in, src, src_stride, in_row, height));
     if (bits == 8) {
         rc = ovs_equalize_histogram_dev(d_in, 1, width, height, in_row, in_bytes, d_flag, device, ctx->stream);
     }
@@ -502,9 +507,8 @@ int ovs_equalize_histogram(const void* src, int width, int height, size_t src_st
         return rc;
     }
     int32_t flag = 0;
-    OVS_HIP(hipMemcpy2DAsync(dst, dst_stride, bits == 8 ? d_in : d_out, width, width, height, hipMemcpyDeviceToHost, ctx->stream));
     OVS_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, ctx->stream));
-    OVS_HIP(hipStreamSynchronize(ctx->stream));
+    OVS_HIP(image_down(ctx, ctx->stream, dst, dst_stride, bits == 8 ? d_in : d_out, width, height));
     if (flag) {
         return ovs::fail(OVS_ERR_UNSUPPORTED, "the 5 % and 95 % levels of the image coincide: the reference divides by zero here");
     }
@@ -600,12 +604,14 @@ int ovs_remap_apply(ovs_remap* r, const uint8_t* src, int src_width, int src_hei
     cv.base = ctx->arena.as<uint8_t>();
     auto* d_in = cv.take<uint8_t>(in_bytes);
     auto* d_out = cv.take<uint8_t>(out_bytes);
-    OVS_HIP(hipMemcpy2DAsync(d_in, src_width, src, src_stride, src_width, src_height, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ctx->mirror.reserve(ctx->arena.bytes)) != OVS_OK) {
+        return rc;
+    }
+    OVS_HIP(image_up(ctx, ctx->stream, d_in, src, src_stride, src_width, src_height));
     if ((rc = ovs_remap_apply_dev(r, d_in, 1, src_width, src_height, src_width, in_bytes, d_out, r->width, out_bytes, ctx->stream)) != OVS_OK) {
         return rc;
     }
-    OVS_HIP(hipMemcpy2DAsync(dst, dst_stride, d_out, r->width, r->width, r->height, hipMemcpyDeviceToHost, ctx->stream));
-    OVS_HIP(hipStreamSynchronize(ctx->stream));
+    OVS_HIP(image_down(ctx, ctx->stream, dst, dst_stride, d_out, r->width, r->height));
     return OVS_OK;
 }
 

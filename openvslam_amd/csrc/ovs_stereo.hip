@@ -472,6 +472,9 @@ int ovs_stereo_compute(const ovs_image_view* left_pyr, const ovs_image_view* rig
     if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
         return rc;
     }
+    if ((rc = ctx->mirror.reserve(ctx->arena.bytes)) != OVS_OK) {
+        return rc;
+    }
     carver cv;
     cv.base = ctx->arena.as<uint8_t>();
     stereo_images im;
@@ -482,7 +485,7 @@ int ovs_stereo_compute(const ovs_image_view* left_pyr, const ovs_image_view* rig
         for (int side = 0; side < 2; ++side) {
             const ovs_image_view& v = *views[side];
             auto* d = cv.take<uint8_t>(static_cast<size_t>(v.width) * v.height);
-            OVS_HIP(hipMemcpy2DAsync(d, v.width, v.data, v.stride, v.width, v.height, hipMemcpyHostToDevice, st));
+            OVS_HIP(image_up(ctx, st, d, v.data, v.stride, static_cast<size_t>(v.width), v.height));
             if (side == 0) {
                 im.l[l] = d;
                 im.ls[l] = v.width;
