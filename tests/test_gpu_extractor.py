@@ -118,3 +118,33 @@ def test_too_small_image_is_rejected():
     ext = orb_extractor(orb_params())
     with pytest.raises(OvsError):
         ext.extract(np.zeros((100, 100), dtype=np.uint8))
+
+
+def test_extract_from_strided_host_buffers():
+    """cv::Mat rows may be padded: the host entry point packs image and mask rows (any stride) before
+    the transfer.  Same result as from a contiguous copy."""
+    import ctypes as C
+    from openvslam_amd import _abi as A
+    from openvslam_amd import _lib
+    w, h, stride, mstride = 333, 241, 333 + 19, 333 + 5
+    img = synth.make_sequence(w, h, 1, seed=77)[0]
+    mask = np.ones((h, w), np.uint8)
+    mask[: h // 5] = 0
+    big = np.full((h, stride), 123, np.uint8)
+    big[:, :w] = img
+    mbig = np.zeros((h, mstride), np.uint8)
+    mbig[:, :w] = mask
+    ext = orb_extractor(orb_params(max_num_keypts=700))
+    want_k, want_d = ext.extract(img, mask)
+    cap = ext.keypoint_capacity(w, h)
+    kps = np.zeros(cap, dtype=A.KEYPOINT_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    _lib.check(_lib.lib().ovs_orb_extract(ext._h, A.ptr(big, A.u8p), w, h, stride, A.ptr(mbig, A.u8p), mstride,
+                                          A.ptr(kps, A.kpp), A.ptr(desc, A.u8p), cap, C.byref(n)))
+    assert n.value == len(want_k) > 100
+    assert np.array_equal(kps[:n.value].view(np.uint8), want_k.view(np.uint8))
+    assert np.array_equal(desc[:n.value], want_d)
+    # and both equal the oracle
+    rk, rd = oracle.OrbExtractor(max_num_keypts=700).extract(img, mask)
+    assert np.array_equal(rk.view(np.uint8), want_k.view(np.uint8)) and np.array_equal(rd, want_d)
