@@ -682,27 +682,26 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         fetch(mq + 64);
         int myacc = -1;
         while (true) {
-            // best and second best listed candidate that no earlier query has claimed: the claim bits of
-            // all listed candidates are fetched together (one LDS round trip), the selection itself
-            // is branch free
             u64 best = kNoKey, second = kNoKey;
             int found = 0;
             if (!done) {
-                u32 bw[kTopK];
-#pragma unroll
-                for (int k = 0; k < kTopK; ++k) {
-                    const u32 idx = key_idx(mykeys[k]);
-                    bw[k] = (excl && mykeys[k] != kNoKey) ? blocked[idx >> 5] >> (idx & 31) : 0u;
-                }
 #pragma unroll
                 for (int k = 0; k < kTopK; ++k) {
                     const u64 key = mykeys[k];
-                    const bool avail = key != kNoKey && !(bw[k] & 1u);
-                    second = (avail && found == 1) ? key : second;
-                    best = (avail && found == 0) ? key : best;
-                    found += avail ? 1 : 0;
+                    if (key != kNoKey && found < 2) {
+                        const u32 idx = key_idx(key);
+                        const bool b = excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u);
+                        if (!b) {
+                            if (found == 0) {
+                                best = key;
+                            }
+                            else {
+                                second = key;
+                            }
+                            ++found;
+                        }
+                    }
                 }
-                found = min(found, 2);
             }
             // A rescan can only matter if an unlisted candidate (whose distance is at least the last
             // listed one) could still be accepted or could change the ratio test.
