@@ -634,27 +634,26 @@ int ovs_stereo_compute_resident(ovs_orb* left, ovs_orb* right,
     auto* d_n = cv.take<int32_t>(2);
     auto* d_status = cv.take<int32_t>(1);
     const int32_t counts[2] = {n_left, n_right};
-    if (nl) {
-        OVS_HIP(hipMemcpyAsync(d_kl, keypts_left, nl * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
-        OVS_HIP(hipMemcpyAsync(d_dl, descs_left, nl * 32, hipMemcpyHostToDevice, st));
+    host_stager hs;
+    if ((rc = hs.init(ctx, st)) != OVS_OK) {
+        return rc;
     }
-    if (nr) {
-        OVS_HIP(hipMemcpyAsync(d_kr, keypts_right, nr * sizeof(ovs_keypoint), hipMemcpyHostToDevice, st));
-        OVS_HIP(hipMemcpyAsync(d_dr, descs_right, nr * 32, hipMemcpyHostToDevice, st));
-    }
-    OVS_HIP(hipMemcpyAsync(d_n, counts, sizeof(counts), hipMemcpyHostToDevice, st));
+    hs.put(d_kl, keypts_left, nl * sizeof(ovs_keypoint));
+    hs.put(d_kr, keypts_right, nr * sizeof(ovs_keypoint));
+    hs.put(d_dl, descs_left, nl * 32);
+    hs.put(d_dr, descs_right, nr * 32);
+    hs.put(d_n, counts, sizeof(counts));
+    OVS_HIP(hs.upload());
     // the pyramids were produced by ovs_orb_extract, which is synchronous: they are complete
     if ((rc = ovs_stereo_compute_batch_dev(left, right, 1, d_kl, d_dl, d_n, d_kr, d_dr, d_n + 1, cap, focal_x_baseline, true_baseline, d_xr, d_depth,
                                            d_status, device, st)) != OVS_OK) {
         return rc;
     }
     int32_t status = 0;
-    if (nl) {
-        OVS_HIP(hipMemcpyAsync(stereo_x_right, d_xr, nl * 4, hipMemcpyDeviceToHost, st));
-        OVS_HIP(hipMemcpyAsync(depths, d_depth, nl * 4, hipMemcpyDeviceToHost, st));
-    }
-    OVS_HIP(hipMemcpyAsync(&status, d_status, 4, hipMemcpyDeviceToHost, st));
-    OVS_HIP(hipStreamSynchronize(st));
+    hs.get(stereo_x_right, d_xr, nl * 4);
+    hs.get(depths, d_depth, nl * 4);
+    hs.get(&status, d_status, 4);
+    OVS_HIP(hs.download());
     if (status != 0) {
         return ovs::fail(status, "keypoint row, octave or patch outside of the image");
     }
