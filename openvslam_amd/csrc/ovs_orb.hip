@@ -445,7 +445,6 @@ constexpr int kTileStride = 72; // bytes per LDS tile row; byte b of a row is im
 // The four pixels are processed as two registers of two u16 lanes ("even" = columns c, c + 2 and
 // "odd" = c + 1, c + 3): every ring operand is one v_perm_b32 that picks its two bytes out of the
 // tile dwords, the rest is v_pk_min/max_u16 and saturating v_pk_sub_u16.
-// Returns dark flags in bits 0..3 and bright flags in bits 4..7 (bit p = pixel c + p).
 typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ pk16 pick2(u32 hi, u32 lo, u32 sel) { return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(hi, lo, sel)); }
@@ -453,14 +452,24 @@ __device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elemen
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ pk16 pk_sub_sat(pk16 a, pk16 b) { return __builtin_elementwise_sub_sat(a, b); }
 
-// bit 0 = e.lo != 0, bit 1 = o.lo != 0, bit 2 = e.hi != 0, bit 3 = o.hi != 0
-__device__ __forceinline__ u32 flags4(pk16 e, pk16 o) {
-    const pk16 one = {1, 1};
-    const u32 y = __builtin_bit_cast(u32, pk_min(e, one)) | (__builtin_bit_cast(u32, pk_min(o, one)) << 1);
-    return (y | (y >> 14)) & 0xFu;
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+    return v;
 }
 
-__device__ __forceinline__ u32 fast_quick_test4(const uint8_t* tile, int trow, int strip, int t) {
+// `cpk` holds 255 - t in both halves.  With D = max over pairs of min(pair), B = min over pairs of
+// max(pair), all values <= 255 in 16-bit lanes:
+//   v - D > t  <=>  sat((v + 255 - t) - D) >= 256      B - v > t  <=>  B + sat((255 - t) - v) >= 256
+// so each flag is bit 8 of a 16-bit lane, i.e. the upper byte of the lane is 0 or 1.  One v_perm
+// collects the four flag bytes of a side in pixel order; the caller turns them into mask bits
+// with one v_dot4 per side.  `xd` / `xb`: byte p = 1 iff pixel c + p passed the dark / bright test.
+__device__ __forceinline__ void fast_quick_flags(const uint8_t* tile, int trow, int strip, pk16 cpk, u32& xd, u32& xb) {
     // dwords strip, strip + 1, strip + 2 of a tile row hold columns c - 4 .. c + 7 (c = first pixel
     // of the strip); selector bytes 0..3 address the second v_perm source, 4..7 the first, 0x0c = 0
     const u32* r0 = reinterpret_cast<const u32*>(tile + trow * kTileStride) + strip;
@@ -490,15 +499,11 @@ __device__ __forceinline__ u32 fast_quick_test4(const uint8_t* tile, int trow, i
     const pk16 dod = pk_max(pk_max(pk_min(x0o, x8o), pk_min(x2o, x10o)), pk_max(pk_min(x4o, x12o), pk_min(x6o, x14o)));
     const pk16 be = pk_min(pk_min(pk_max(x0e, x8e), pk_max(x2e, x10e)), pk_min(pk_max(x4e, x12e), pk_max(x6e, x14e)));
     const pk16 bo = pk_min(pk_min(pk_max(x0o, x8o), pk_max(x2o, x10o)), pk_min(pk_max(x4o, x12o), pk_max(x6o, x14o)));
-    const pk16 tt = {(unsigned short)t, (unsigned short)t};
-    // v - D > t  /  B - v > t, as saturating differences
-    const pk16 sde = pk_sub_sat(pk_sub_sat(ve, de), tt), sdo = pk_sub_sat(pk_sub_sat(vo, dod), tt);
-    const pk16 sbe = pk_sub_sat(pk_sub_sat(be, ve), tt), sbo = pk_sub_sat(pk_sub_sat(bo, vo), tt);
-    const u32 any = __builtin_bit_cast(u32, sde) | __builtin_bit_cast(u32, sdo) | __builtin_bit_cast(u32, sbe) | __builtin_bit_cast(u32, sbo);
-    if (any == 0) {
-        return 0;
-    }
-    return flags4(sde, sdo) | (flags4(sbe, sbo) << 4);
+    const u32 fde = __builtin_bit_cast(u32, pk_sub_sat(ve + cpk, de)), fdo = __builtin_bit_cast(u32, pk_sub_sat(vo + cpk, dod));
+    const u32 fbe = __builtin_bit_cast(u32, be + pk_sub_sat(cpk, ve)), fbo = __builtin_bit_cast(u32, bo + pk_sub_sat(cpk, vo));
+    constexpr u32 kFlagBytes = 0x07030501u; // (even.b1, odd.b1, even.b3, odd.b3) = pixels c .. c + 3
+    xd = __builtin_amdgcn_perm(fdo, fde, kFlagBytes);
+    xb = __builtin_amdgcn_perm(fbo, fbe, kFlagBytes);
 }
 
 // One side of the exact score for a pixel that passed the rejection test on that side.  `inv` is 0
@@ -582,24 +587,55 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     // at byte c + 4 of its row (strips of four interior pixels are dword aligned in LDS)
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    for (int i = tid; i < th * 18; i += 256) {
-        const int r = i / 18, k = i - r * 18;
-        const int x = min_x - 1 + 4 * k;
-        const uint8_t* src = img + (long long)(min_y + r) * pitch;
-        u32 v;
-        if (x + 3 < g.w) {
-            v = load_u32_unaligned(src + x);
-        }
-        else {
-            v = 0;
+    if (min_x + 71 <= g.w) {
+        // every tile dword lies inside its image row: a wave fetches three rows at a time (18
+        // lanes per row), all six fetches of a lane in flight before the first LDS write.  Each
+        // fetch is the aligned dword pair around the address.
+        const int lr = (lane * 57) >> 10; // lane / 18 for lane < 64
+        const int kk = lane - 18 * lr;
+        const int r0 = wave * 3 + lr;
+        const uint8_t* base = img + (long long)min_y * pitch + (min_x - 1);
+        const u32 mis = (u32)(reinterpret_cast<uintptr_t>(base) & 3);
+        const uint8_t* base_al = base - mis;
+        const u32 row_step = 12u * (u32)pitch;
+        u32 off = (u32)r0 * (u32)pitch + 4u * (u32)kk + mis;
+        u32 lo[6], hi[6], sh[6];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (x + b < g.w) {
-                    v |= (u32)src[x + b] << (8 * b);
-                }
+        for (int j = 0; j < 6; ++j) {
+            const bool on = lr < 3 && r0 + 12 * j < th;
+            sh[j] = off & 3u;
+            const u32* q = reinterpret_cast<const u32*>(base_al + (off & ~3u));
+            lo[j] = on ? q[0] : 0u;
+            hi[j] = (on && sh[j]) ? q[1] : 0u;
+            off += row_step;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (lr < 3 && r0 + 12 * j < th) {
+                reinterpret_cast<u32*>(tile)[(r0 + 12 * j) * 18 + kk] = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh[j]);
             }
         }
-        reinterpret_cast<u32*>(tile)[r * 18 + k] = v;
+    }
+    else {
+        for (int i = tid; i < th * 18; i += 256) {
+            const int r = i / 18, k = i - r * 18;
+            const int x = min_x - 1 + 4 * k;
+            const uint8_t* src = img + (long long)(min_y + r) * pitch;
+            u32 v;
+            if (x + 3 < g.w) {
+                v = load_u32_unaligned(src + x);
+            }
+            else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (x + b < g.w) {
+                        v |= (u32)src[x + b] << (8 * b);
+                    }
+                }
+            }
+            reinterpret_cast<u32*>(tile)[r * 18 + k] = v;
+        }
     }
     for (int i = tid; i < 66 * 68 / 4; i += 256) {
         reinterpret_cast<u32*>(score)[i] = 0;
@@ -608,6 +644,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 
     int thr = min(max(p.ini_thr, 0), 255);
     const int min_thr = min(max(p.min_thr, 0), 255);
+    // stage A geometry of this thread: strip of four columns, rows r_first + 16 k; two mask bits
+    // per pixel, set for the pixels inside the interior
+    const int strip = tid & 15, r_first = tid >> 4;
+    u32 valid_bits = 0;
+    {
+        const u32 cols = (1u << (2 * min(max(iw - 4 * strip, 0), 4))) - 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (r_first + 16 * k < ih) {
+                valid_bits |= cols << (8 * k);
+            }
+        }
+    }
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         if (tid == 0) {
@@ -618,42 +667,38 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
             keep32[tid] = 0;
         }
         __syncthreads();
-        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread.  Survivors are
-        // appended to the work list by wave-level compaction: one ballot per pixel position gives
-        // every lane its offset (v_mbcnt), one LDS atomic per wave reserves the range.  An item is
-        // row << 6 | column, bit 12 = passed the dark test, bit 13 = passed the bright test.
-        const int strip = tid & 15;
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const int r = (tid >> 4) + 16 * k;
-            u32 m = 0;
-            if (r < ih && 4 * strip < iw) {
-                m = fast_quick_test4(tile, r + 3, strip, thr);
-                const u32 valid = (1u << min(iw - 4 * strip, 4)) - 1u;
-                m &= valid | (valid << 4);
-            }
-            const u32 px = (m | (m >> 4)) & 0xFu;
-            const u64 any = __ballot(px != 0);
-            if (any) {
-                u64 bal[4];
-                int cnt = 0;
+        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread (rows r, r + 16,
+        // r + 32, r + 48).  Bit 2 * (4 * k + j) of `m` = pixel j of strip-row k passed the dark
+        // test, the next bit = it passed the bright test (one v_dot4 per side turns four flag
+        // bytes into mask bits).  Survivors are appended to the work list: a wave prefix sum over
+        // the per-lane counts, one LDS atomic per wave, then every lane writes its own items.  An
+        // item is row << 6 | column, bit 12 = passed the dark test, bit 13 = the bright test.
+        {
+            const pk16 cpk = {(unsigned short)(255 - thr), (unsigned short)(255 - thr)};
+            u32 acc[4];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    bal[b] = __ballot((px >> b) & 1u);
-                    cnt += __popcll(bal[b]);
-                }
+            for (int k = 0; k < 4; ++k) {
+                u32 xd, xb;
+                fast_quick_flags(tile, r_first + 16 * k + 3, strip, cpk, xd, xb);
+                acc[k] = __builtin_amdgcn_udot4(xb, 0x80200802u, __builtin_amdgcn_udot4(xd, 0x40100401u, 0u, false), false);
+            }
+            const u32 m = (acc[0] | (acc[1] << 8) | (acc[2] << 16) | (acc[3] << 24)) & valid_bits;
+            u32 px = (m | (m >> 1)) & 0x55555555u;
+            const int cnt = __popc(px);
+            const int incl = wave_incl_scan(cnt);
+            const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+            if (wave_total) {
                 int base = 0;
                 if (lane == 0) {
-                    base = atomicAdd(&nwork, cnt);
+                    base = atomicAdd(&nwork, wave_total);
                 }
-                base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if ((px >> b) & 1u) {
-                        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal[b], 0u));
-                        work[pos] = (unsigned short)((r << 6) | (4 * strip + b) | (((m >> b) & 1u) << 12) | (((m >> (b + 4)) & 1u) << 13));
-                    }
-                    base += __popcll(bal[b]);
+                int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+                const u32 item0 = ((u32)r_first << 6) | (4u * (u32)strip);
+                while (px) {
+                    const u32 b = (u32)__builtin_ctz(px); // 2 * (4 * k + j)
+                    px &= px - 1u;
+                    // k << 10 (row + 16 k) | j | side flags << 12
+                    work[pos++] = (unsigned short)(item0 + ((b & 0x18u) << 7) + ((b >> 1) & 3u) + (((m >> b) & 3u) << 12));
                 }
             }
         }
