@@ -204,9 +204,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=765, help="frames matched per step and GPU (a multiple of --streams)")
+    ap.add_argument("--batch", type=int, default=1020, help="frames matched per step and GPU (a multiple of --streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3, help="contiguous sub-batches of the step's batch in flight on separate HIP streams (each re-extracts one halo frame)")
+    ap.add_argument("--streams", type=int, default=4, help="contiguous sub-batches of the step's batch in flight on separate HIP streams (each re-extracts one halo frame)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
 

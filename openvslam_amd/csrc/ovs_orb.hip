@@ -1892,6 +1892,10 @@ struct ovs_orb {
     ovs::dev_buffer st_img, st_mask, st_out;  // st_out: count (256 B), keypoints, descriptors
     ovs::pinned_buffer pin_in, pin_out;
     hipStream_t own_stream = nullptr;
+    // the blur runs beside FAST + quadtree on a second stream (fork after the pyramid, join before
+    // the descriptors)
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // state of the last extraction (for the pyramid accessors)
     const uint8_t* last_img0 = nullptr;
@@ -2259,6 +2263,15 @@ void ovs_orb_destroy(ovs_orb* h) {
     if (h->own_stream) {
         (void)hipStreamDestroy(h->own_stream);
     }
+    if (h->side_stream) {
+        (void)hipStreamDestroy(h->side_stream);
+    }
+    if (h->ev_fork) {
+        (void)hipEventDestroy(h->ev_fork);
+    }
+    if (h->ev_join) {
+        (void)hipEventDestroy(h->ev_join);
+    }
     delete h;
 }
 
@@ -2402,13 +2415,34 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
             OVS_LAUNCH("k_resize_linear", k_resize_linear, grid, block, 0, stream, p, src, h->tabs.as<int>(), l);
         }
     }
+    // FAST (vector-issue bound) and the quadtree (latency bound) on the caller's stream, the blur
+    // (bandwidth bound) beside them on the handle's second stream.  While per-kernel timing is on,
+    // everything stays on one stream so that each launch is measured alone.
+    const bool forked = !ovs::timing_enabled();
+    hipStream_t blur_stream = stream;
+    if (forked) {
+        if (!h->side_stream) {
+            OVS_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            OVS_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            OVS_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+        blur_stream = h->side_stream;
+        OVS_HIP(hipEventRecord(h->ev_fork, stream));
+        OVS_HIP(hipStreamWaitEvent(blur_stream, h->ev_fork, 0));
+    }
+    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, blur_stream,
+               p, src, h->blur.as<uint8_t>(), n_frames);
+    if (forked) {
+        OVS_HIP(hipEventRecord(h->ev_join, blur_stream));
+    }
     OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells * n_frames)), dim3(256), 0, stream,
                p, src, h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
-    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, stream,
-               p, src, h->blur.as<uint8_t>(), n_frames);
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
+    if (forked) {
+        OVS_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
+    }
     const int od_blocks = std::max((std::min(p.kp_total_cap, cap) + 15) / 16, 1);
     OVS_LAUNCH("k_orient_desc", k_orient_desc, dim3(xcd_grid(static_cast<long long>(od_blocks) * n_frames)), dim3(256), 0, stream,
                p, src, h->blur.as<uint8_t>(), h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(),
