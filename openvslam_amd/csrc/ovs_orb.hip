@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -2418,7 +2419,13 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     // FAST (vector-issue bound) and the quadtree (latency bound) on the caller's stream, the blur
     // (bandwidth bound) beside them on the handle's second stream.  While per-kernel timing is on,
     // everything stays on one stream so that each launch is measured alone.
-    const bool forked = !ovs::timing_enabled();
+    // OVS_SERIAL_EXTRACT=1 in the environment keeps them on one stream as well (profiler runs that
+    // want every kernel's duration undisturbed).
+    static const bool serial_env = [] {
+        const char* e = std::getenv("OVS_SERIAL_EXTRACT");
+        return e && e[0] == '1';
+    }();
+    const bool forked = !ovs::timing_enabled() && !serial_env;
     hipStream_t blur_stream = stream;
     if (forked) {
         if (!h->side_stream) {

@@ -9,6 +9,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# every kernel alone on the device: no second stream inside the extractor
+export OVS_SERIAL_EXTRACT=1
 cd /tmp
 BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch 255 --streams 1"
 
