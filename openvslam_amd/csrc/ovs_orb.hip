@@ -1189,18 +1189,19 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
 // and deep: moving the candidates to their child nodes and voting into the child counters of the
 // NEXT sweep are one pass (the counters are double buffered), and each thread issues four loads
 // before it touches the first result.
+constexpr int kCandDepth = 4; // candidate loads a thread keeps in flight
 template <typename F>
 __device__ __forceinline__ void for_each_candidate(uint2* __restrict__ cand, int N, F&& f) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i0 = tid; i0 < N; i0 += 4 * nt) {
-        uint2 cd[4];
+    for (int i0 = tid; i0 < N; i0 += kCandDepth * nt) {
+        uint2 cd[kCandDepth];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kCandDepth; ++u) {
             const int i = i0 + u * nt;
             cd[u] = cand[min(i, N - 1)];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kCandDepth; ++u) {
             const int i = i0 + u * nt;
             if (i < N) {
                 f(i, cd[u]);

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
 #pragma unroll
                 for (int k = 0; k < kTopK; ++k) {
                     const u64 key = mykeys[k];
-                    if (key != kNoKey && found < 2) {
+                    if (key != kNoKey && found < needed) { // the runner-up only matters to the ratio tests
                         const u32 idx = key_idx(key);
                         const bool b = excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u);
                         if (!b) {
