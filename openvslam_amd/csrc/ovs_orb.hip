@@ -1210,11 +1210,66 @@ __device__ __forceinline__ void for_each_candidate(uint2* __restrict__ cand, int
     }
 }
 
+// One pass that moves every candidate from its node `n` of the current list to a node `nn` of the
+// list being built and votes for the next split of `nn`.  The per-candidate work is a chain of
+// dependent LDS reads (node record -> child id -> record of the child) that ends in an LDS atomic,
+// and an atomic keeps the thread's later LDS reads behind it; the chain is therefore walked for a
+// whole batch of candidates at a time, stage by stage, so that a batch costs three LDS round trips
+// instead of five per candidate.
+//   stage1(n)                      an extra word read together with the record of node n
+//   stage2(n, rec, b, aux, x, y)   the new node id (may read one more LDS word)
+template <typename Stage1, typename Stage2>
+__device__ __forceinline__ void move_and_vote(uint2* __restrict__ cand, int N, const u32* nc_from, const short4* nb_from,
+                                              const u32* nc_to, const short4* nb_to, u32* votes, Stage1&& stage1, Stage2&& stage2) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i0 = tid; i0 < N; i0 += kCandDepth * nt) {
+        uint2 cd[kCandDepth];
+#pragma unroll
+        for (int u = 0; u < kCandDepth; ++u) {
+            cd[u] = cand[min(i0 + u * nt, N - 1)];
+        }
+        u32 rec[kCandDepth], aux[kCandDepth];
+        short4 b[kCandDepth];
+#pragma unroll
+        for (int u = 0; u < kCandDepth; ++u) {
+            const u32 n = cd[u].y & kCnt;
+            rec[u] = nc_from[n];
+            b[u] = nb_from[n];
+            aux[u] = stage1(n);
+        }
+        u32 nn[kCandDepth];
+#pragma unroll
+        for (int u = 0; u < kCandDepth; ++u) {
+            nn[u] = stage2(cd[u].y & kCnt, rec[u], b[u], aux[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16));
+        }
+        u32 rec2[kCandDepth];
+        short4 b2[kCandDepth];
+#pragma unroll
+        for (int u = 0; u < kCandDepth; ++u) {
+            rec2[u] = nc_to[nn[u]];
+            b2[u] = nb_to[nn[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kCandDepth; ++u) {
+            const int i = i0 + u * nt;
+            if (i < N) {
+                cand[i].y = (cd[u].y & 0xFF000000u) | nn[u];
+                if (!(rec2[u] & kLeaf)) {
+                    atomicAdd(&votes[4 * nn[u] + child_of(b2[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16))], 1u);
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* __restrict__ slots, const u32* __restrict__ cell_counts,
                                                          uint2* __restrict__ cand_all,
                                                          u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count) {
     extern __shared__ u32 smem[];
-    const int level = blockIdx.x, frame = blockIdx.y;
+    // Workgroups are dealt round-robin to the 8 XCDs in launch order and a level-0 workgroup runs
+    // about three times as long as one of the last level: with the frame as the fast grid dimension
+    // every XCD gets the same mix of levels, and the long workgroups start first.
+    const int level = blockIdx.y, frame = blockIdx.x;
     const level_geom& g = p.lv[level];
     const int tid = threadIdx.x, nt = blockDim.x;
     const int ncap = p.max_ncap;
@@ -1290,20 +1345,27 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             }
             v[u] = slots[(cell0 + lo) * kSlotsPerCell + (i - (int)cellpref[lo])];
         }
+        // all LDS reads of the batch before its first LDS atomic: an atomic orders every later LDS
+        // access of the thread behind it
+        u32 ni[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const u32 x = v[u] & 0xFFFu, y = (v[u] >> 12) & 0xFFFu;
+            u32 ix = 0, iy = 0;
+            for (int k = 1; k < g.nx; ++k) {
+                ix += x >= thx[k];
+            }
+            for (int k = 1; k < g.ny; ++k) {
+                iy += y >= thy[k];
+            }
+            ni[u] = min(ix + iy * (unsigned)g.nx, (unsigned)(n0 - 1));
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * nt < N) {
                 const u32 x = v[u] & 0xFFFu, y = (v[u] >> 12) & 0xFFFu, r = v[u] >> 24;
-                u32 ix = 0, iy = 0;
-                for (int k = 1; k < g.nx; ++k) {
-                    ix += x >= thx[k];
-                }
-                for (int k = 1; k < g.ny; ++k) {
-                    iy += y >= thy[k];
-                }
-                const u32 ni = min(ix + iy * (unsigned)g.nx, (unsigned)(n0 - 1));
-                cand[idx[u]] = make_uint2(x | (y << 16), (r << 24) | ni);
-                atomicAdd(&t0[ni], 1u);
+                cand[idx[u]] = make_uint2(x | (y << 16), (r << 24) | ni[u]);
+                atomicAdd(&t0[ni[u]], 1u);
             }
         }
     }
@@ -1331,13 +1393,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     }
     __syncthreads();
     // compact node ids + votes for the first sweep
-    for_each_candidate(cand, N, [&](int i, uint2 cd) {
-        const u32 n = t1[cd.y & kCnt];
-        cand[i].y = (cd.y & 0xFF000000u) | n;
-        if (!(nc_cur[n] & kLeaf)) {
-            atomicAdd(&cc[4 * n + child_of(nb_cur[n], cd.x & 0xFFFF, cd.x >> 16)], 1u);
-        }
-    });
+    move_and_vote(
+        cand, N, t1, nb_cur, nc_cur, nb_cur, cc, [&](u32) { return 0u; },
+        [&](u32, u32 compact_id, short4, u32, int, int) { return compact_id; });
     __syncthreads();
 
     bool filled = false;
@@ -1351,14 +1409,16 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         if (tid == 0) {
             sh[0] = 0;
         }
+        // one scan for both prefix sums: children created before node q in the low half, leaves
+        // before it in the high half (both stay below 2^16: at most 4 * ncap children)
         for (int q = tid; q < S; q += nt) {
             const bool leaf = nc_cur[q] & kLeaf;
-            t0[q] = leaf ? 0 : nonzero4(&cc[4 * q]);
-            t1[q] = leaf ? 1 : 0;
+            t0[q] = leaf ? 0x10000u : (u32)nonzero4(&cc[4 * q]);
         }
         __syncthreads();
-        const int C = (int)block_excl_scan(t0, S, red);
-        const int Lf = (int)block_excl_scan(t1, S, red);
+        const u32 both = block_excl_scan(t0, S, red);
+        const int C = (int)(both & 0xFFFFu);
+        const int Lf = (int)(both >> 16);
         const int Snew = C + Lf;
         if (Snew > ncap) {
             overflow = true;
@@ -1367,19 +1427,20 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         u32 local_pool = 0;
         for (int q = tid; q < S; q += nt) {
             if (nc_cur[q] & kLeaf) {
-                const int qn = C + t1[q];
+                const int qn = C + (int)(t0[q] >> 16);
                 nb_nxt[qn] = nb_cur[q];
                 nc_nxt[qn] = nc_cur[q];
                 cc[4 * q] = qn;
             }
             else {
                 const short4 b = nb_cur[q];
+                const int created_before = (int)(t0[q] & 0xFFFFu);
                 int r = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const u32 k = cc[4 * q + c];
                     if (k) {
-                        const int qn = C - 1 - ((int)t0[q] + r);
+                        const int qn = C - 1 - (created_before + r);
                         nb_nxt[qn] = child_bounds(b, c);
                         nc_nxt[qn] = k;
                         cc[4 * q + c] = qn;
@@ -1397,15 +1458,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         }
         __syncthreads();
         // move every candidate to its child and vote for the next split of that child
-        for_each_candidate(cand, N, [&](int i, uint2 cd) {
-            const u32 n = cd.y & kCnt;
-            const int x = cd.x & 0xFFFF, y = cd.x >> 16;
-            const u32 nn = (nc_cur[n] & kLeaf) ? cc[4 * n] : cc[4 * n + child_of(nb_cur[n], x, y)];
-            cand[i].y = (cd.y & 0xFF000000u) | nn;
-            if (!(nc_nxt[nn] & kLeaf)) {
-                atomicAdd(&cc2[4 * nn + child_of(nb_nxt[nn], x, y)], 1u);
-            }
-        });
+        move_and_vote(
+            cand, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32) { return 0u; },
+            [&](u32 n, u32 rec, short4 b, u32, int x, int y) { return cc[4 * n + ((rec & kLeaf) ? 0 : child_of(b, x, y))]; });
         const int pool = (int)sh[0];
         __syncthreads();
         {
@@ -1525,15 +1580,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             cc2[i] = 0;
         }
         __syncthreads();
-        for_each_candidate(cand, N, [&](int i, uint2 cd) {
-            const u32 n = cd.y & kCnt;
-            const int x = cd.x & 0xFFFF, y = cd.x >> 16;
-            const u32 nn = (nc_cur[n] & kProc) ? cc[4 * n + child_of(nb_cur[n], x, y)] : Cn + t3[n];
-            cand[i].y = (cd.y & 0xFF000000u) | nn;
-            if (!(nc_nxt[nn] & kLeaf)) {
-                atomicAdd(&cc2[4 * nn + child_of(nb_nxt[nn], x, y)], 1u);
-            }
-        });
+        move_and_vote(
+            cand, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32 n) { return t3[n]; },
+            [&](u32 n, u32 rec, short4 b, u32 kept_before, int x, int y) {
+                const u32 child_id = cc[4 * n + ((rec & kProc) ? child_of(b, x, y) : 0)];
+                return (rec & kProc) ? child_id : (u32)Cn + kept_before;
+            });
         __syncthreads();
         {
             short4* tb = nb_cur;
@@ -2445,7 +2497,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     }
     OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells * n_frames)), dim3(256), 0, stream,
                p, src, h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
-    OVS_LAUNCH("k_quadtree", k_quadtree, dim3(p.num_levels, n_frames), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
+    OVS_LAUNCH("k_quadtree", k_quadtree, dim3(n_frames, p.num_levels), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
     if (forked) {
