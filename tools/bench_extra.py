@@ -21,7 +21,7 @@ import torch
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from openvslam_amd import _abi as A  # noqa: E402
-from openvslam_amd import _lib, synth  # noqa: E402
+from openvslam_amd import _lib, match, synth  # noqa: E402
 from openvslam_amd.feature import orb_extractor, orb_params  # noqa: E402
 
 
@@ -166,6 +166,19 @@ def live(args):
             ext.extract(f)
             n += 1
     mono_ms = (time.perf_counter() - t0) / n * 1e3
+    # projection::match_current_and_last_frames of two consecutive frames, host buffers in and out
+    k0, d0 = ext.extract(frames[0])
+    k1, d1 = ext.extract(frames[1])
+    view = A.make_frame_view(k1, d1, ext.get_scale_factors(), A.make_grid(0.0, 0.0, float(w), float(h)))
+    xy = np.stack([k0["x"] - 3.0, k0["y"] - 1.0], axis=1).astype(np.float32)
+    q = A.make_proj_queries(xy, k0["octave"], d0, angle=k0["angle"])
+    matcher = match.projection(0.9, True)
+    for _ in range(3):
+        matcher.match_current_and_last_frames(view, q, 20.0)
+    t0 = time.perf_counter()
+    for _ in range(args.steps * 10):
+        num_matches, _m = matcher.match_current_and_last_frames(view, q, 20.0)
+    match_ms = (time.perf_counter() - t0) / (args.steps * 10) * 1e3
     sw, sh = 752, 480
     left, right = synth.make_stereo_pair(sw, sh, seed=100)[:2]
     el, er = orb_extractor(orb_params(max_num_keypts=1000)), orb_extractor(orb_params(max_num_keypts=1000))
@@ -186,7 +199,8 @@ def live(args):
         stereo_frame()
     stereo_ms = (time.perf_counter() - t0) / (args.steps * 10) * 1e3
     return {"metric": "live single-frame latency, host buffers in and out", "value": 1e3 / mono_ms, "unit": "frames/s",
-            "mono_1241x376_2000kp_ms_per_frame": mono_ms, "stereo_752x480_1000kp_ms_per_pair": stereo_ms}
+            "mono_1241x376_2000kp_ms_per_frame": mono_ms, "stereo_752x480_1000kp_ms_per_pair": stereo_ms,
+            "projection_match_ms": match_ms, "projection_queries": int(len(k0)), "projection_matches": int(num_matches)}
 
 
 def main():
