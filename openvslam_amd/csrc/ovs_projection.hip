@@ -608,8 +608,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool IN_LDS, bool FUSE>
-__global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp, int lds_n) {
+// KIND >= 0 compiles the kernel for that one matcher (the kind tests fold away, which matters here:
+// the kernel is a single wavefront whose time is its instruction count); -1 = any kind.
+template <bool IN_LDS, bool FUSE, int KIND = -1>
+__global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp_arg, int lds_n) {
+    proj_params pp = pp_arg;
+    if (KIND >= 0) {
+        pp.kind = KIND;
+    }
     extern __shared__ u32 sm[];
     __shared__ u32 hist[32];
     __shared__ u32 order[32];
@@ -1045,7 +1051,19 @@ int launch_resolve_t(const proj_problem* d_prob, int n_problems, int max_n, cons
     const int lds_n = resolve_lds_n(max_n);
     const size_t bytes = resolve_lds_bytes(max_n, lds_n);
     if (lds_n > 0) {
-        OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        // the per-frame matchers of the tracking thread get a kernel compiled for their kind
+        if (!FUSE && pp.kind == kCurrLast) {
+            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kCurrLast>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        }
+        else if (!FUSE && pp.kind == kFrameLms) {
+            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kFrameLms>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        }
+        else if (!FUSE && pp.kind == kRange) {
+            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kRange>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        }
+        else {
+            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        }
     }
     else {
         if (bytes > 64 * 1024) {
