@@ -543,7 +543,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
     __shared__ int rowbase[65];
     __shared__ int nwork;
+    __shared__ int ncorner;
     __shared__ int total;
+    constexpr int kWorkHalf = 2048;
+    bool compact = false;
 
     const int blk = xcd_contiguous_block(p.total_cells * n_frames);
     if (blk < 0) {
@@ -648,8 +651,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     // stage A geometry of this thread: strip of four columns, rows r_first + 16 k; two mask bits
     // per pixel, set for the pixels inside the interior
     const int strip = tid & 15, r_first = tid >> 4;
-    u32 valid_bits = 0;
-    {
+    u32 valid_bits = 0xFFFFFFFFu;
+    if (iw < 64 || ih < 64) { // a window cut by the image border (same decision in every thread)
+        valid_bits = 0;
         const u32 cols = (1u << (2 * min(max(iw - 4 * strip, 0), 4))) - 1u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -662,6 +666,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
     for (int pass = 0; pass < 2; ++pass) {
         if (tid == 0) {
             nwork = 0;
+            ncorner = 0;
             total = 0;
         }
         if (tid < 128) {
@@ -706,8 +711,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
         __syncthreads();
         // stage B: exact score of the survivors from the side that passed (a pixel that passed the
         // test on one side only cannot reach the threshold on the other, so the side score
-        // decides; both sides for the rare pixel that passed both); below the threshold: 0
+        // decides; both sides for the rare pixel that passed both); below the threshold: 0.
+        // Items that reach the threshold go to a second list in the upper half of `work` (when
+        // the first list leaves it free), the suppression pass then only walks those.
         const int nw = nwork;
+        compact = nw <= kWorkHalf;
         for (int i = tid; i < nw; i += 256) {
             const u32 item = work[i];
             const int r = (item >> 6) & 63, c = item & 63;
@@ -716,13 +724,19 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
             if ((item & 0x3000u) == 0x3000u) {
                 sc = max(sc, fast_side_score(centre, 0xFF) - 1);
             }
-            score[(r + 1) * 68 + c + 1] = (uint8_t)(sc >= thr ? sc : 0);
+            const bool corner = sc >= thr;
+            score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
+            if (compact && corner) {
+                work[kWorkHalf + atomicAdd(&ncorner, 1)] = (unsigned short)item;
+            }
         }
         __syncthreads();
-        // non-maximum suppression over the survivors (every other pixel scores below the threshold)
-        int mykept = 0;
-        for (int i = tid; i < nw; i += 256) {
-            const u32 item = work[i];
+        // non-maximum suppression (every pixel that is not on the list scores 0); in compact mode
+        // the kept items are collected at the start of `work`, which nobody reads any more
+        const unsigned short* nms_list = compact ? work + kWorkHalf : work;
+        const int nms_n = compact ? ncorner : nw;
+        for (int i = tid; i < nms_n; i += 256) {
+            const u32 item = nms_list[i];
             const int r = (item >> 6) & 63, c = item & 63;
             const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
             const int sc = sp[0];
@@ -733,19 +747,18 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 #pragma unroll
                     for (int dx = -1; dx <= 1; ++dx) {
                         if (dy != 0 || dx != 0) {
-                            const int nbv = sp[dy * 68 + dx];
-                            m = max(m, nbv >= thr ? nbv : 0);
+                            m = max(m, (int)sp[dy * 68 + dx]);
                         }
                     }
                 }
                 if (sc > m) {
                     atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
-                    ++mykept;
+                    const int k = atomicAdd(&total, 1);
+                    if (compact) {
+                        work[k] = (unsigned short)item;
+                    }
                 }
             }
-        }
-        if (mykept) {
-            atomicAdd(&total, mykept);
         }
         __syncthreads();
         if (total != 0 || pass == 1 || min_thr == thr) {
@@ -761,7 +774,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
         return;
     }
 
-    const int n_items = nwork;
+    const int n_items = compact ? total : nwork; // the kept items, or every survivor of the rejection test
     if (s.mask) {
         // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
         for (int i = tid; i < n_items; i += 256) {
