@@ -50,6 +50,21 @@ def test_extract_low_texture_uses_min_threshold():
     _compare(img, max_num_keypts=1000)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "salt_pepper", "checker"])
+def test_extract_dense_corner_images(kind):
+    # images in which most pixels pass the FAST rejection test: the per-cell survivor list runs
+    # past the half the compacted lists need, and the dense fallback of the kernel is exercised
+    rng = np.random.default_rng(11)
+    if kind == "uniform":
+        img = rng.integers(0, 256, (240, 320), dtype=np.uint8)
+    elif kind == "salt_pepper":
+        img = np.where(rng.random((240, 320)) < 0.5, 0, 255).astype(np.uint8)
+    else:
+        yy, xx = np.mgrid[0:240, 0:320]
+        img = (((xx // 2 + yy // 2) & 1) * 200 + rng.integers(0, 40, (240, 320))).astype(np.uint8)
+    _compare(img, max_num_keypts=1000)
+
+
 def test_extract_flat_image_has_no_keypoints():
     img = np.full((480, 640), 77, dtype=np.uint8)
     gk, gd = _compare(img, max_num_keypts=500)
