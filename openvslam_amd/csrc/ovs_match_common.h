@@ -57,6 +57,23 @@ __device__ __forceinline__ u64 group_min_u64(u64 v) {
     return v;
 }
 
+// minimum over aligned groups of W lanes, in every lane of the group; 8-lane groups stay inside the
+// vector ALU (two quad permutes and the half-row mirror as DPP operands of v_min_u32)
+template <int W>
+__device__ __forceinline__ u32 group_min_u32(u32 v) {
+    if (W == 8) {
+        v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));  // quad_perm [1,0,3,2]
+        v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));  // quad_perm [2,3,0,1]
+        v = min(v, (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false)); // row_half_mirror
+        return v;
+    }
+#pragma unroll
+    for (int d = W / 2; d >= 1; d >>= 1) {
+        v = min(v, (u32)__shfl_xor(v, d, W));
+    }
+    return v;
+}
+
 template <int W>
 __device__ __forceinline__ u32 group_sum_u32(u32 v) {
 #pragma unroll

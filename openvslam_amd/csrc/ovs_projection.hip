@@ -331,7 +331,8 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
     return true;
 }
 
-// key = distance (9 bits) << 40 | scan position (20 bits) << 20 | keypoint index (20 bits)
+// list key = distance (9 bits) << 40 | tie-break position (20 bits: the entry index, monotone in the
+// reference's scan position) << 20 | keypoint index (20 bits)
 __device__ __forceinline__ u64 make_key(u32 dist, u32 pos, u32 idx) { return ((u64)dist << 40) | ((u64)pos << 20) | idx; }
 __device__ __forceinline__ u32 key_dist(u64 k) { return (u32)(k >> 40); }
 __device__ __forceinline__ u32 key_idx(u64 k) { return (u32)(k & 0xFFFFFu); }
@@ -415,14 +416,29 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
 }
 
 // Scan of one query window by a group of G lanes that share the query.  Returns (in every lane of
-// the group) the K smallest keys among the keypoints that pass all gates; `total` counts them.
+// the group) the K best candidates among the keypoints that pass all gates, best first, as 32-bit
+// selection keys; `total` counts the candidates.
+//
+// Selection key = distance << 20 | entry index j in the searched frame's CSR order.  The scan walks
+// the window's columns in ascending order and each column's entries in ascending j, and the CSR is
+// stored column-major, so the scan position the reference breaks distance ties with is monotone in
+// j: ordering by (distance, j) is the reference's order.  32-bit keys make the per-lane insertion a
+// min / max pair per slot and the group minimum three DPP instructions.
+constexpr u32 kNoKey32 = 0xFFFFFFFFu;
+__device__ __forceinline__ u32 sel_dist(u32 k) { return k >> 20; }
+__device__ __forceinline__ u32 sel_entry(u32 k) { return k & 0xFFFFFu; }
+// the list format of the resolve kernel: distance, tie-break position, keypoint index
+__device__ __forceinline__ u64 list_key(const frame_dev& f, u32 sel) {
+    return sel == kNoKey32 ? kNoKey : make_key(sel_dist(sel), sel_entry(sel), f.g_entry[sel_entry(sel)].w);
+}
+
 template <int G, int K, bool FUSE>
 __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* qd, const uint8_t* occupied,
-                            const u32* blocked, u64 (&top)[K], u32& total) {
+                            const u32* blocked, u32 (&top)[K], u32& total) {
     const int gl = threadIdx.x & (G - 1);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        top[k] = kNoKey;
+        top[k] = kNoKey32;
     }
     total = 0;
     window w;
@@ -435,12 +451,12 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
     }
     const int R = (int)f.grid.num_rows;
     const int ncx = c.ranged ? 1 : w.max_cx - w.min_cx + 1;
-    u64 loc[K];
+    u32 loc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        loc[k] = kNoKey;
+        loc[k] = kNoKey32;
     }
-    u32 cnt = 0, posbase = 0;
+    u32 cnt = 0;
     for (int cb = 0; cb < ncx; cb += G) {
         u32 s = 0, e = 0;
         if (c.ranged) {
@@ -483,32 +499,29 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
                     const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
                     const u32 dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w)
                                      + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
-                    u64 key = make_key(dist, posbase + t, en.w);
+                    u32 key = (dist << 20) | j;
                     ++cnt;
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
-                        if (key < loc[k]) {
-                            const u64 tmp = loc[k];
-                            loc[k] = key;
-                            key = tmp;
-                        }
+                        const u32 small = min(loc[k], key);
+                        key = max(loc[k], key);
+                        loc[k] = small;
                     }
                 }
             }
         }
-        posbase += T;
     }
     total = group_sum_u32<G>(cnt);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const u64 m = group_min_u64<G>(loc[0]);
+        const u32 m = group_min_u32<G>(loc[0]);
         top[k] = m;
-        if (loc[0] == m && m != kNoKey) {
+        if (loc[0] == m && m != kNoKey32) {
 #pragma unroll
             for (int t = 0; t + 1 < K; ++t) {
                 loc[t] = loc[t + 1];
             }
-            loc[K - 1] = kNoKey;
+            loc[K - 1] = kNoKey32;
         }
     }
 }
@@ -522,11 +535,11 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
     if (qi >= P.q.n) {
         return;
     }
-    u64 top[kTopK];
+    u32 top[kTopK];
     u32 total = 0;
 #pragma unroll
     for (int k = 0; k < kTopK; ++k) {
-        top[k] = kNoKey;
+        top[k] = kNoKey32;
     }
     query_ctx c;
     if (P.q.valid[qi]) {
@@ -543,12 +556,12 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
     for (int part = 0; part < (kTopK + kGroup - 1) / kGroup; ++part) {
         const int slot = part * kGroup + gl;
         if (slot < kTopK) {
-            u64 v = top[0];
+            u32 v = top[0];
 #pragma unroll
             for (int k = 1; k < kTopK; ++k) {
                 v = slot == k ? top[k] : v;
             }
-            P.lists[(size_t)qi * kTopK + slot] = v;
+            P.lists[(size_t)qi * kTopK + slot] = list_key(P.frm, v);
         }
     }
     if (gl == 0) {
@@ -793,9 +806,10 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 make_query_ctx<FUSE>(pp, P.frm, P.q, qi, c);
                 u32 qd[8];
                 load_desc(P.q.desc + 32 * (size_t)qi, qd);
-                u64 top2[2];
+                u32 sel2[2];
                 u32 t2;
-                window_topk<64, 2, FUSE>(P.frm, c, qd, P.occupied, blocked, top2, t2);
+                window_topk<64, 2, FUSE>(P.frm, c, qd, P.occupied, blocked, sel2, t2);
+                const u64 top2[2] = {list_key(P.frm, sel2[0]), list_key(P.frm, sel2[1])};
                 if (top2[0] != kNoKey && accept_rule(pp, P.frm, top2[0], top2[1])) {
                     const u32 ridx = key_idx(top2[0]);
                     const bool rblocks = __shfl((int)blocks, stop) != 0;
