@@ -1055,13 +1055,32 @@ __global__ __launch_bounds__(256) void k_entries_from_list(const u32* __restrict
 
 // ---- host side ------------------------------------------------------------------------------------
 // LDS plan of k_proj_resolve: the claim bitmap always lives in LDS; the per-keypoint `matched` and
-// `claim` arrays join it when everything fits in 64 KB.
-int resolve_lds_n(int n) { return (static_cast<size_t>(n) * 8 + (static_cast<size_t>(n) / 32 + 2) * 4 <= 60 * 1024) ? std::max(n, 1) : 0; }
+// `claim` arrays join it when everything fits in 150 KB (a workgroup is one wavefront and a launch
+// has one workgroup per problem, so one workgroup per compute unit may as well take its LDS).
+int resolve_lds_n(int n) { return (static_cast<size_t>(n) * 8 + (static_cast<size_t>(n) / 32 + 2) * 4 <= 150 * 1024) ? std::max(n, 1) : 0; }
 size_t resolve_lds_bytes(int n, int lds_n) {
     if (lds_n > 0) {
         return (static_cast<size_t>((lds_n + 31) / 32) + 1) * 4 + static_cast<size_t>(lds_n) * 8;
     }
     return (static_cast<size_t>((n + 31) / 32) + 1) * 4;
+}
+
+// launches one instance of the resolve kernel; dynamic LDS beyond the default limit is requested
+// once per instance and size
+template <typename Kernel>
+int launch_resolve_instance(Kernel kernel, const proj_problem* d_prob, int n_problems, size_t bytes, int lds_n, const proj_params& pp, hipStream_t st) {
+    if (bytes > 48 * 1024) {
+        static thread_local size_t granted = 0; // per instance (the template argument is the function's type only: keyed below)
+        static thread_local const void* granted_for = nullptr;
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        if (granted_for != fn || granted < bytes) {
+            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+            granted_for = fn;
+            granted = bytes;
+        }
+    }
+    OVS_LAUNCH("k_proj_resolve", kernel, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+    return OVS_OK;
 }
 
 template <bool FUSE>
@@ -1071,26 +1090,17 @@ int launch_resolve_t(const proj_problem* d_prob, int n_problems, int max_n, cons
     if (lds_n > 0) {
         // the per-frame matchers of the tracking thread get a kernel compiled for their kind
         if (!FUSE && pp.kind == kCurrLast) {
-            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kCurrLast>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+            return launch_resolve_instance(k_proj_resolve<true, false, kCurrLast>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        else if (!FUSE && pp.kind == kFrameLms) {
-            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kFrameLms>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        if (!FUSE && pp.kind == kFrameLms) {
+            return launch_resolve_instance(k_proj_resolve<true, false, kFrameLms>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        else if (!FUSE && pp.kind == kRange) {
-            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, false, kRange>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
+        if (!FUSE && pp.kind == kRange) {
+            return launch_resolve_instance(k_proj_resolve<true, false, kRange>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        else {
-            OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<true, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
-        }
+        return launch_resolve_instance(k_proj_resolve<true, FUSE>, d_prob, n_problems, bytes, lds_n, pp, st);
     }
-    else {
-        if (bytes > 64 * 1024) {
-            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_resolve<false, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        static_cast<int>(bytes)));
-        }
-        OVS_LAUNCH("k_proj_resolve", (k_proj_resolve<false, FUSE>), dim3(n_problems), dim3(64), bytes, st, d_prob, pp, 0);
-    }
-    return OVS_OK;
+    return launch_resolve_instance(k_proj_resolve<false, FUSE>, d_prob, n_problems, bytes, 0, pp, st);
 }
 
 bool kind_is_fuse(int kind) { return kind == kFuseDetect || kind == kFuseReplace; }
