@@ -42,7 +42,7 @@ struct stereo_images {
 
 __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restrict__ kr, const int* __restrict__ n_ptr, int n_fixed,
                                                      stereo_images im, u32* __restrict__ row_start, u32* __restrict__ row_items, int items_cap,
-                                                     int* __restrict__ err) {
+                                                     int lds_items, int* __restrict__ err) {
     extern __shared__ u32 sm[];
     __shared__ u32 red[8];
     const int pair = blockIdx.y;
@@ -120,30 +120,47 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
         return;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const ovs_keypoint kp = kr[i];
-        if (kp.octave < 0 || im.num_levels <= kp.octave) {
-            continue;
+    // scatter the keypoint indices into their rows, then order every row's list (the reference
+    // appends in keypoint order); done in LDS when the pair's lists fit behind the row tables
+    // (`lds_items` words), the per-row insertion sorts being chains of dependent accesses
+    auto fill_and_sort = [&](u32* items) {
+        for (int i = tid; i < n; i += 256) {
+            const ovs_keypoint kp = kr[i];
+            if (kp.octave < 0 || im.num_levels <= kp.octave) {
+                continue;
+            }
+            const float r = __fmul_rn(2.0f, im.scale[kp.octave]);
+            const int max_r = cv_ceil_ff(__fadd_rn(kp.y, r));
+            const int min_r = cv_floor_ff(__fsub_rn(kp.y, r));
+            for (int row = max(min_r, 0); row <= min(max_r, rows - 1); ++row) {
+                items[atomicAdd(&cur[row], 1u)] = (u32)i;
+            }
         }
-        const float r = __fmul_rn(2.0f, im.scale[kp.octave]);
-        const int max_r = cv_ceil_ff(__fadd_rn(kp.y, r));
-        const int min_r = cv_floor_ff(__fsub_rn(kp.y, r));
-        for (int row = max(min_r, 0); row <= min(max_r, rows - 1); ++row) {
-            row_items[atomicAdd(&cur[row], 1u)] = (u32)i;
+        __syncthreads();
+        for (int row = tid; row < rows; row += 256) {
+            const u32 b = cnt[row], e = cnt[row + 1];
+            for (u32 i = b + 1; i < e; ++i) {
+                const u32 v = items[i];
+                u32 j = i;
+                while (j > b && items[j - 1] > v) {
+                    items[j] = items[j - 1];
+                    --j;
+                }
+                items[j] = v;
+            }
+        }
+    };
+    const u32 total_items = cnt[rows];
+    if (total_items <= (u32)lds_items) {
+        u32* litems = sm + 2 * rows + 1;
+        fill_and_sort(litems);
+        __syncthreads();
+        for (u32 i = tid; i < total_items; i += 256) {
+            row_items[i] = litems[i];
         }
     }
-    __syncthreads();
-    for (int row = tid; row < rows; row += 256) {
-        const u32 b = cnt[row], e = cnt[row + 1];
-        for (u32 i = b + 1; i < e; ++i) {
-            const u32 v = row_items[i];
-            u32 j = i;
-            while (j > b && row_items[j - 1] > v) {
-                row_items[j] = row_items[j - 1];
-                --j;
-            }
-            row_items[j] = v;
-        }
+    else {
+        fill_and_sort(row_items);
     }
 }
 
@@ -405,12 +422,15 @@ int launch_stereo(const stereo_images& im, const ovs_keypoint* d_kl, const uint8
                   u32* d_row_start, u32* d_row_items, int items_cap, int* d_corr, int* d_err,
                   float* d_x_right, float* d_depth, hipStream_t st, int n_pairs = 1) {
     const int rows = im.lh[0];
-    const size_t lds = (2 * static_cast<size_t>(rows) + 1) * sizeof(u32);
-    if (lds > 64 * 1024) {
+    const size_t lds_tables = (2 * static_cast<size_t>(rows) + 1) * sizeof(u32);
+    if (lds_tables > 64 * 1024) {
         return ovs::fail(OVS_ERR_UNSUPPORTED, "images taller than 8190 rows are not supported by the stereo matcher");
     }
+    // the rest of 60 KB holds the row lists while they are built
+    const int lds_items = lds_tables < 60 * 1024 ? static_cast<int>(std::min<size_t>((60 * 1024 - lds_tables) / sizeof(u32), static_cast<size_t>(std::max(items_cap, 0)))) : 0;
+    const size_t lds = lds_tables + static_cast<size_t>(lds_items) * sizeof(u32);
     const float max_disp = focal_x_baseline / true_baseline; // stereo.cc:16
-    OVS_LAUNCH("k_stereo_rows", k_stereo_rows, dim3(1, n_pairs), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, d_err);
+    OVS_LAUNCH("k_stereo_rows", k_stereo_rows, dim3(1, n_pairs), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, lds_items, d_err);
     if (cap_l > 0) {
         OVS_LAUNCH("k_stereo_match", k_stereo_match, dim3((cap_l + 256 / kSG - 1) / (256 / kSG), n_pairs), dim3(256), 0, st,
                    d_kl, d_dl, d_nl, nl, d_kr, d_dr, im, d_row_start, d_row_items, focal_x_baseline, max_disp, d_x_right, d_depth, d_corr, d_err);
