@@ -128,7 +128,11 @@ int ovs_orb_extract(ovs_orb* h, const uint8_t* img, int width, int height, size_
  *   d_imgs       n_frames images, row_stride bytes per row, frame_stride bytes per frame
  *   d_mask       optional level-0 mask shared by all frames (NULL: rectangle mask / none)
  *   d_kps        n_frames x cap keypoints; d_desc n_frames x cap x 32 bytes; d_counts n_frames
- *   stream       hipStream_t; work is enqueued, not synchronised.
+ *   stream       hipStream_t; work is enqueued, not synchronised.  The blur runs on a second stream
+ *                owned by the handle, forked from `stream` after the pyramid and joined before the
+ *                descriptors with events (legal under stream capture); everything the call enqueues
+ *                is complete when `stream` reaches the point after the call.  OVS_SERIAL_EXTRACT=1 in
+ *                the environment keeps all kernels on `stream`.
  * A frame whose keypoint count exceeds `cap` gets d_counts[f] = -(count) and truncated output. */
 int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, int width, int height,
                               size_t row_stride, size_t frame_stride,
