@@ -52,10 +52,21 @@ def stereo(args):
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
     L = _lib.lib()
 
+    # the two extractions on two streams, as data::frame runs them on two threads (frame.cc:64-67);
+    # the matcher waits for both
+    right_stream = torch.cuda.Stream(dev)
+    right_done = torch.cuda.Event()
+
     def step():
-        st = torch.cuda.current_stream(dev).cuda_stream
-        for ext, img, (k, d, c) in ((el, left, bufs[0]), (er, right, bufs[1])):
-            ext.extract_batch_dev(img.data_ptr(), batch, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, st)
+        main = torch.cuda.current_stream(dev)
+        st = main.cuda_stream
+        right_stream.wait_stream(main)  # the previous step's matcher still reads the right pyramid
+        k, d, c = bufs[1]
+        er.extract_batch_dev(right.data_ptr(), batch, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, right_stream.cuda_stream)
+        right_done.record(right_stream)
+        k, d, c = bufs[0]
+        el.extract_batch_dev(left.data_ptr(), batch, w, h, w, w * h, k.data_ptr(), d.data_ptr(), c.data_ptr(), cap, st)
+        main.wait_event(right_done)
         _lib.check(L.ovs_stereo_compute_batch_dev(el._h, er._h, batch, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), bufs[0][2].data_ptr(),
                                                   bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), cap,
                                                   np.float32(fxb), np.float32(fxb / fx), xr.data_ptr(), dep.data_ptr(), status.data_ptr(), 0, st))
