@@ -64,6 +64,37 @@ def test_stereo_compute_matches_oracle(w, h, n, seed):
     assert np.median(err) < 1.0
 
 
+def test_stereo_row_lists_larger_than_lds():
+    # 4000 right keypoints on the coarse levels span 11..16 image rows each: their row lists (about
+    # 50 k entries) do not fit in the LDS the row kernel builds them in, and it builds them in global
+    # memory instead
+    w, h = 752, 480
+    left, right, _, _ = synth.make_stereo_pair(w, h, seed=9)
+    ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=1000), oracle.OrbExtractor(max_num_keypts=1000)
+    kl, dl = ref_l.extract(left)
+    kr, dr = ref_r.extract(right)
+    keep = (kr["y"] > 20) & (kr["y"] < h - 20)
+    kr, dr = kr[keep], dr[keep]
+    kr = np.ascontiguousarray(np.tile(kr, 4))
+    dr = np.ascontiguousarray(np.tile(dr, (4, 1)))
+    kr["octave"] = 5 + (np.arange(len(kr)) % 3)
+    la, keep_l = _views([ref_l.pyramid_level(i) for i in range(8)])
+    ra, keep_r = _views([ref_r.pyramid_level(i) for i in range(8)])
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    isf = oracle.scale_table("inv_scale_factors", 8, 1.2)
+    res = []
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        xr = np.full(len(kl), 7.0, dtype=np.float32)
+        dep = np.full(len(kl), 7.0, dtype=np.float32)
+        rc = getattr(lib_, prefix + "stereo_compute")(la, ra, 8, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr),
+                                                      A.ptr(dl, A.u8p), A.ptr(dr, A.u8p), A.ptr(sf, A.f32p), A.ptr(isf, A.f32p),
+                                                      np.float32(FXB), np.float32(FXB / FX), A.ptr(xr, A.f32p), A.ptr(dep, A.f32p), *extra)
+        res.append((rc, xr, dep))
+    assert res[0][0] == res[1][0] == 0
+    assert _same_float(res[0][1], res[1][1]) and _same_float(res[0][2], res[1][2])
+    assert (res[0][1] >= 0).sum() > 10
+
+
 def test_stereo_compute_dev_matches_oracle():
     w, h, n = 752, 480, 1000
     dev = torch.device("cuda", 0)
