@@ -3,12 +3,13 @@
 // descriptors, batched over frames.  Replaces feature::orb_extractor::extract()
 // (src/openvslam/feature/orb_extractor.cc:68-144) and everything it calls.
 //
-// Pipeline per batch (all launches on one stream, no host synchronisation in between):
+// Pipeline per batch (no host synchronisation in between):
 //   k_resize_linear   x (levels-1)   level k from level k-1        (orb_extractor.cc:263-272)
 //   k_fast_cells      x 1            one workgroup per 64-px cell  (orb_extractor.cc:274-369)
-//   k_gauss7          x 1            all levels, all frames        (orb_extractor.cc:132-133)
+//   k_gauss7          x 1            all levels, all frames, beside FAST + quadtree on the
+//                                    handle's second stream        (orb_extractor.cc:132-133)
 //   k_quadtree        x 1            one workgroup per (frame, level) (orb_extractor.cc:398-590)
-//   k_orient_desc     x 1            one wavefront per keypoint    (orb_extractor.cc:592-702)
+//   k_orient_desc     x 1            16 lanes per keypoint         (orb_extractor.cc:592-702)
 //
 // Data layout in HBM (per handle, sized for the largest batch seen):
 //   pyramid   levels 1..L-1, [level][frame][h_l][pitch_l] u8, pitch_l = w_l rounded up to 64
@@ -374,52 +375,15 @@ __global__ __launch_bounds__(256) void k_resize_rows(plan_dev p, image_src s, co
 // arc maximum and hi = max over the arcs of the arc minimum.  A = max(v - lo, hi - v) is the
 // largest t + 1 for which the pixel is still a FAST-9 corner at threshold t, hence
 //   corner at threshold t  <=>  A - 1 >= t,   and OpenCV's cornerScore of a corner is A - 1
-// independent of the threshold it was detected with.  The score plane S = max(A - 1, 0) is
-// therefore computed once per pixel with no divergence, and both thresholds (initial, and the
-// minimum one when the cell stays empty, orb_extractor.cc:340-347) only differ in the
-// suppression pass: a pixel is kept iff S >= t and S > S' for all 8 neighbours with S' >= t.
-// Survivors are written in raster order (row ballots + prefix over rows).
+// independent of the threshold it was detected with.  A pixel is kept iff S = A - 1 >= t and
+// S > S' for all 8 neighbours with S' >= t.  The kernel runs this for the initial threshold and,
+// when the cell stays empty, once more for the minimum one (orb_extractor.cc:340-347), in stages:
+//   A  a cheap necessary test on every pixel (four opposite ring pairs), survivors -> work list
+//   B  the exact score of the survivors, the ones that reach the threshold -> second list
+//   C  suppression over the second list, the kept ones -> third list and a 64 x 64 bitmap
+//   D  mask test and output of the kept ones in raster order (row prefix over the bitmap)
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
-__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
-
-__device__ __forceinline__ int fast_score_9_16(const uint8_t* c, int stride) {
-    int x[16];
-    x[0] = c[3 * stride];
-    x[1] = c[3 * stride + 1];
-    x[2] = c[2 * stride + 2];
-    x[3] = c[stride + 3];
-    x[4] = c[3];
-    x[5] = c[-stride + 3];
-    x[6] = c[-2 * stride + 2];
-    x[7] = c[-3 * stride + 1];
-    x[8] = c[-3 * stride];
-    x[9] = c[-3 * stride - 1];
-    x[10] = c[-2 * stride - 2];
-    x[11] = c[-stride - 3];
-    x[12] = c[-3];
-    x[13] = c[stride - 3];
-    x[14] = c[2 * stride - 2];
-    x[15] = c[3 * stride - 1];
-    const int v = c[0];
-    // sliding window of 9 over the circular ring by doubling: 3, 3+3 -> 6 (overlap-free), 9
-    int mx3[16], mn3[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mx3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
-        mn3[k] = min3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
-    }
-    int lo = 255, hi = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int amax = max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
-        const int amin = min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
-        lo = min(lo, amax);
-        hi = max(hi, amin);
-    }
-    const int a = max(v - lo, hi - v);
-    return max(a - 1, 0);
-}
 
 __device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, unsigned x, float scale) {
     // is_in_mask of orb_extractor.cc:278-280: mask.at<uchar>(y * scale, x * scale) == 0
@@ -428,11 +392,6 @@ __device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, uns
     my = min(max(my, 0), s.mask_h - 1);
     mx = min(max(mx, 0), s.mask_w - 1);
     return s.mask[(long long)my * s.mask_stride + mx] == 0;
-}
-
-// byte `o` (0..11) of the 12-byte window {a, b, c}
-__device__ __forceinline__ int win_byte(u32 a, u32 b, u32 c, int o) {
-    return o < 4 ? (int)((a >> (8 * o)) & 0xFF) : (o < 8 ? (int)((b >> (8 * (o - 4))) & 0xFF) : (int)((c >> (8 * (o - 8))) & 0xFF));
 }
 
 constexpr int kTileStride = 72; // bytes per LDS tile row; byte b of a row is image column min_x - 1 + b
@@ -831,24 +790,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
 // k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact integer row pass, column pass
 // (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int reflect101(int p, int len) {
-    if ((unsigned)p < (unsigned)len) {
-        return p;
-    }
-    if (len == 1) {
-        return 0;
-    }
-    do {
-        if (p < 0) {
-            p = -p;
-        }
-        else {
-            p = 2 * len - 2 - p;
-        }
-    } while ((unsigned)p >= (unsigned)len);
-    return p;
-}
-
 constexpr int kBlurRows = 64;  // output rows per wave tile
 constexpr int kBlurCols = 256; // output columns per wave tile (four per lane)
 
@@ -886,14 +827,6 @@ struct blur_row {
 __device__ __forceinline__ int reflect101_near(int p, int len) {
     p = p < 0 ? -p : p;
     return p >= len ? 2 * len - 2 - p : p;
-}
-
-__device__ __forceinline__ u32 load_quad(__amdgpu_buffer_rsrc_t plane, const u32 (&off)[4], u32 row_off) {
-    const u32 b0 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[0], row_off, 0);
-    const u32 b1 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[1], row_off, 0);
-    const u32 b2 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[2], row_off, 0);
-    const u32 b3 = __builtin_amdgcn_raw_buffer_load_b8(plane, off[3], row_off, 0);
-    return b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 
 // Per-lane, per-tile constants of the row pass.

@@ -976,16 +976,23 @@ __global__ __launch_bounds__(256) void k_window_list(frame_dev f, int nq, const 
 
 // Fills the problem descriptors of a batch of consecutive-frame matches from device-side counts and
 // splits the query fields out of the previous frame's keypoints.  grid = (ceil(cap / 256), n_frames).
+struct scale_table {
+    float v[64];
+};
+
 __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restrict__ kps, const uint8_t* __restrict__ desc,
                                                      const int* __restrict__ counts, int n_frames, int cap,
                                                      const float* __restrict__ reproj_xy, ovs_grid grid,
-                                                     const float* __restrict__ scale_factors, int num_levels,
+                                                     float* __restrict__ scale_factors, scale_table sf_host, int num_levels,
                                                      u32* cell_start, uint4* g_entry, uint4* g_desc, int ncell,
                                                      int* sl, float* ang, uint8_t* valid, u64* lists, u32* totals, int* acc,
                                                      int* matched, u32* num_matches, int* err, proj_problem* problems) {
     const int f = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (f == 0) {
+        if (i < num_levels) {
+            scale_factors[i] = sf_host.v[i]; // the caller's table travels as a kernel argument: no copy to order
+        }
         if (i < cap) {
             matched[i] = -1;
         }
@@ -1882,11 +1889,13 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
     auto* d_lists = cv.take<u64>(fc * kTopK);
     auto* d_err = cv.take<int>(1);
     auto* d_prob = cv.take<proj_problem>(F);
-    OVS_HIP(hipMemcpyAsync(d_sf, scale_factors, static_cast<size_t>(num_scale_levels) * 4, hipMemcpyHostToDevice, st));
+    scale_table sf_arg;
+    std::memset(&sf_arg, 0, sizeof(sf_arg));
+    std::memcpy(sf_arg.v, scale_factors, static_cast<size_t>(num_scale_levels) * sizeof(float));
 
     proj_params pp{kCurrLast, margin, OVS_DIR_NONE, num_scale_levels, 0.0f, kThrHigh, check_orientation, 1, 0};
     OVS_LAUNCH("k_batch_setup", k_batch_setup, dim3((cap + 255) / 256, n_frames), dim3(256), 0, st,
-               d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, num_scale_levels,
+               d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, sf_arg, num_scale_levels,
                d_cell_start, d_entry, d_gdesc, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,
                d_matched, d_num_matches, d_err, d_prob);
     OVS_LAUNCH("k_grid_build", k_grid_build, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
