@@ -554,6 +554,35 @@ int ovs_map_keyframe_rows(const ovs_map_file* m, int32_t* ids, int64_t* row_offs
 /* descs: num_descriptors x 32 bytes */
 int ovs_map_copy_descriptors(const ovs_map_file* m, uint8_t* descs);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Keypoints to bearing vectors (the step of data::frame construction between undistortion and  */
+/* grid assignment, src/openvslam/data/frame.cc:36-51)                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* camera::model_type_t (src/openvslam/camera/base.h:22-26) */
+enum { OVS_CAMERA_PERSPECTIVE = 0, OVS_CAMERA_FISHEYE = 1, OVS_CAMERA_EQUIRECTANGULAR = 2 };
+
+/* The camera parameters the conversion reads: fx_, fy_, cx_, cy_ (double) of the perspective and
+ * fisheye models, cols_ / rows_ (unsigned int) of the equirectangular one. */
+typedef struct ovs_camera {
+    int32_t model;
+    uint32_t cols, rows;
+    int32_t reserved;
+    double fx, fy, cx, cy;
+} ovs_camera;
+
+/* camera::perspective::convert_keypoints_to_bearings (src/openvslam/camera/perspective.cc:130-138),
+ * camera::fisheye::convert_keypoints_to_bearings (camera/fisheye.cc:169-177),
+ * camera::equirectangular::convert_keypoints_to_bearings (camera/equirectangular.cc:45-56).
+ *   undist_keypts  undistorted keypoints; bearings out, 3 doubles per keypoint (Vec3_t)
+ * Device variant: n_frames x cap keypoints, d_counts (n_frames, or NULL = cap each) limits the
+ * entries converted per frame, d_bearings n_frames x cap x 3; enqueued on `stream`. */
+int ovs_convert_keypoints_to_bearings_dev(const ovs_camera* cam, const ovs_keypoint* d_undist_keypts,
+                                          const int32_t* d_counts, int n_frames, int cap,
+                                          double* d_bearings, int device, void* stream);
+int ovs_convert_keypoints_to_bearings(const ovs_camera* cam, const ovs_keypoint* undist_keypts, int n,
+                                      double* bearings, int device);
+
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points
  * keep their scratch memory per (host thread, device, stream), so independent batches may be in

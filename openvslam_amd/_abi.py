@@ -72,6 +72,15 @@ class Knn2(C.Structure):
 
 
 knn2p = C.POINTER(Knn2)
+
+CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR = 0, 1, 2
+
+
+class Camera(C.Structure):
+    _fields_ = [("model", C.c_int32), ("cols", C.c_uint32), ("rows", C.c_uint32), ("reserved", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
 assert C.sizeof(Knn2) == 24 and C.sizeof(Keypoint) == 28
 
 

@@ -132,6 +132,8 @@ def _declare(L):
     L.ovs_knn2_merge_dev.argtypes = [vp, i, i, vp, vp]
     L.ovs_match_batch_current_and_last_dev.argtypes = [vp, vp, vp, i, i, vp, C.POINTER(A.Grid), A.f32p, i,
                                                        C.c_float, i, vp, vp, i, vp]
+    L.ovs_convert_keypoints_to_bearings_dev.argtypes = [C.POINTER(A.Camera), vp, vp, i, i, vp, i, vp]
+    L.ovs_convert_keypoints_to_bearings.argtypes = [C.POINTER(A.Camera), A.kpp, i, A.f64p, i]
 
 
 def timing_report():

@@ -383,6 +383,40 @@ private:
 
 } // namespace util
 
+namespace camera {
+
+// camera::perspective::convert_keypoints_to_bearings (camera/perspective.cc:130-138) and
+// camera::fisheye::convert_keypoints_to_bearings (camera/fisheye.cc:169-177): `cam` is the caller's
+// camera object (fx_, fy_, cx_, cy_), `bearings` the caller's eigen_alloc_vector<Vec3_t>
+// (three doubles per element), resized as the reference does.
+template <class Camera, class KeyPoint, class BearingVec>
+void convert_keypoints_to_bearings(const Camera& cam, const std::vector<KeyPoint>& undist_keypts, BearingVec& bearings,
+                                   int model = OVS_CAMERA_PERSPECTIVE, int device = 0) {
+    static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout");
+    static_assert(sizeof(typename BearingVec::value_type) == 3 * sizeof(double), "Vec3_t layout");
+    ovs_camera c{};
+    c.model = model;
+    c.fx = cam.fx_; c.fy = cam.fy_; c.cx = cam.cx_; c.cy = cam.cy_;
+    bearings.resize(undist_keypts.size());
+    check(ovs_convert_keypoints_to_bearings(&c, reinterpret_cast<const ovs_keypoint*>(undist_keypts.data()), static_cast<int>(undist_keypts.size()),
+                                            reinterpret_cast<double*>(bearings.data()), device));
+}
+
+// camera::equirectangular::convert_keypoints_to_bearings (camera/equirectangular.cc:45-56): cols_, rows_
+template <class Camera, class KeyPoint, class BearingVec>
+void convert_keypoints_to_bearings_equirectangular(const Camera& cam, const std::vector<KeyPoint>& undist_keypts, BearingVec& bearings, int device = 0) {
+    static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout");
+    static_assert(sizeof(typename BearingVec::value_type) == 3 * sizeof(double), "Vec3_t layout");
+    ovs_camera c{};
+    c.model = OVS_CAMERA_EQUIRECTANGULAR;
+    c.cols = cam.cols_; c.rows = cam.rows_;
+    bearings.resize(undist_keypts.size());
+    check(ovs_convert_keypoints_to_bearings(&c, reinterpret_cast<const ovs_keypoint*>(undist_keypts.data()), static_cast<int>(undist_keypts.size()),
+                                            reinterpret_cast<double*>(bearings.data()), device));
+}
+
+} // namespace camera
+
 namespace match {
 
 // match/base.h:65-75

@@ -207,6 +207,10 @@ int ovo_match_batch_current_and_last(const ovs_keypoint* kps, const uint8_t* des
                                      float margin, int check_orientation,
                                      int32_t* matched, uint32_t* num_matches);
 
+/* camera::*::convert_keypoints_to_bearings (camera/perspective.cc:130-138, fisheye.cc:169-177,
+ * equirectangular.cc:45-56) */
+int ovo_convert_keypoints_to_bearings(const ovs_camera* cam, const ovs_keypoint* undist_keypts, int n, double* bearings);
+
 #ifdef __cplusplus
 }
 #endif

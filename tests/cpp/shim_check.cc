@@ -103,6 +103,8 @@ struct camera {
         return true;
     }
 };
+struct pinhole { double fx_ = 500, fy_ = 250, cx_ = 320, cy_ = 240; };
+struct sphere { unsigned int cols_ = 640, rows_ = 320; };
 struct frame;
 
 struct landmark {
@@ -299,6 +301,17 @@ int main(int argc, char** argv) {
     int eq_min = 255, eq_max = 0;
     for (int i = 0; i < w * h; ++i) { eq_min = std::min<int>(eq_min, rect_l.data[i]); eq_max = std::max<int>(eq_max, rect_l.data[i]); }
     const bool pre_ok = gray_ok && rect_ok && eq_min == 0 && eq_max == 255;
+    // bearings: the principal point looks along +z, the image centre of a panorama as well
+    std::vector<mock::keypoint> at_centre(3);
+    at_centre[0].x = 320; at_centre[0].y = 240;
+    at_centre[1].x = 820; at_centre[1].y = 240;      // x_n = 1
+    at_centre[2].x = 320; at_centre[2].y = 160;      // panorama centre
+    std::vector<mock::vec3> bearings;
+    camera::convert_keypoints_to_bearings(mock::pinhole{}, at_centre, bearings);
+    bool bearings_ok = bearings.size() == 3 && bearings[0](0) == 0.0 && bearings[0](1) == 0.0 && bearings[0](2) == 1.0
+                       && bearings[1](0) == 1.0 / std::sqrt(2.0) && bearings[1](2) == 1.0 / std::sqrt(2.0);
+    camera::convert_keypoints_to_bearings_equirectangular(mock::sphere{}, at_centre, bearings);
+    bearings_ok = bearings_ok && std::fabs(bearings[2](0)) < 1e-15 && std::fabs(bearings[2](1)) < 1e-15 && std::fabs(bearings[2](2) - 1.0) < 1e-15;
     // stereo: frame 1 is frame 0 seen dx pixels to the left, i.e. a right camera image with disparity dx
     feature::orb_extractor ext_r(prm);
     std::vector<mock::keypoint> kps_r;
@@ -365,12 +378,12 @@ int main(int argc, char** argv) {
     for (auto& lm : lms2) replaced += lm->erased;
     for (auto& lm : lms) { replaced += lm->erased; adopted += lm->is_observed_in_keyframe(&frm[1]); }
     std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u "
-                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d stereo %u/%u\n",
+                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d bearings %d stereo %u/%u\n",
                 frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow, n_rkf, n_tri, n_area, n_mutual,
-                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0, n_stereo_ok, n_stereo);
+                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0, bearings_ok ? 1 : 0, n_stereo_ok, n_stereo);
     const bool ok = n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100
                     && n_rkf > 50 && n_rkf <= n_bf && n_tri == tri_pairs.size() && n_tri > 50 && n_area > 50 && area_moved == n_area
                     && n_mutual == mutual_written && n_mutual > 100 && n_detect == dup_written && n_detect > 100 && n_replace == replaced
-                    && n_replace > 100 && adopted > 50 && pre_ok && stereo_ok;
+                    && n_replace > 100 && adopted > 50 && pre_ok && bearings_ok && stereo_ok;
     return ok ? 0 : 2;
 }
