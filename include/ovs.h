@@ -562,13 +562,17 @@ int ovs_map_copy_descriptors(const ovs_map_file* m, uint8_t* descs);
 /* camera::model_type_t (src/openvslam/camera/base.h:22-26) */
 enum { OVS_CAMERA_PERSPECTIVE = 0, OVS_CAMERA_FISHEYE = 1, OVS_CAMERA_EQUIRECTANGULAR = 2 };
 
-/* The camera parameters the conversion reads: fx_, fy_, cx_, cy_ (double) of the perspective and
- * fisheye models, cols_ / rows_ (unsigned int) of the equirectangular one. */
+/* The camera parameters the two conversions read: fx_, fy_, cx_, cy_ (double) of the perspective
+ * and fisheye models and their distortion parameters in the order of cv_dist_params_ -- k1, k2, p1,
+ * p2, k3 for perspective (camera/perspective.cc:22), k1, k2, k3, k4 for fisheye (camera/fisheye.cc:22)
+ * -- and cols_ / rows_ (unsigned int) of the equirectangular one.  The bearing conversion does not
+ * read `dist`. */
 typedef struct ovs_camera {
     int32_t model;
     uint32_t cols, rows;
     int32_t reserved;
     double fx, fy, cx, cy;
+    double dist[5];
 } ovs_camera;
 
 /* camera::perspective::convert_keypoints_to_bearings (src/openvslam/camera/perspective.cc:130-138),
@@ -582,6 +586,23 @@ int ovs_convert_keypoints_to_bearings_dev(const ovs_camera* cam, const ovs_keypo
                                           double* d_bearings, int device, void* stream);
 int ovs_convert_keypoints_to_bearings(const ovs_camera* cam, const ovs_keypoint* undist_keypts, int n,
                                       double* bearings, int device);
+
+/* camera::perspective::undistort_keypoints (camera/perspective.cc:99-128: cv::undistortPoints with
+ * R empty, P = the camera matrix and the termination criterion 20 iterations / 1e-6),
+ * camera::fisheye::undistort_keypoints (camera/fisheye.cc:139-167: cv::fisheye::undistortPoints),
+ * camera::equirectangular::undistort_keypoints (camera/equirectangular.cc:41-43: a copy).
+ * The reference hands OpenCV the camera matrix and the distortion parameters as float matrices
+ * (perspective.cc:21-22, fisheye.cc:21-22); the narrowing happens inside these entry points.
+ *   undist_keypts  pt undistorted; angle, size, octave copied; response 0 and class_id -1 (the
+ *                  defaults of cv::KeyPoint) for perspective / fisheye, the whole record copied for
+ *                  equirectangular
+ * Device variant: as above; d_bearings (n_frames x cap x 3 doubles) may be NULL, otherwise the
+ * bearing of every undistorted keypoint is written by the same launch. */
+int ovs_undistort_keypoints_dev(const ovs_camera* cam, const ovs_keypoint* d_dist_keypts,
+                                const int32_t* d_counts, int n_frames, int cap,
+                                ovs_keypoint* d_undist_keypts, double* d_bearings, int device, void* stream);
+int ovs_undistort_keypoints(const ovs_camera* cam, const ovs_keypoint* dist_keypts, int n,
+                            ovs_keypoint* undist_keypts, int device);
 
 /* Concurrency of the device-pointer entry points: an extractor / database handle serves one call
  * at a time (its buffers belong to the stream of the last call), while the matcher entry points

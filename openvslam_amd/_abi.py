@@ -78,7 +78,7 @@ CAMERA_PERSPECTIVE, CAMERA_FISHEYE, CAMERA_EQUIRECTANGULAR = 0, 1, 2
 
 class Camera(C.Structure):
     _fields_ = [("model", C.c_int32), ("cols", C.c_uint32), ("rows", C.c_uint32), ("reserved", C.c_int32),
-                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("dist", C.c_double * 5)]
 
 
 assert C.sizeof(Knn2) == 24 and C.sizeof(Keypoint) == 28

@@ -134,6 +134,8 @@ def _declare(L):
                                                        C.c_float, i, vp, vp, i, vp]
     L.ovs_convert_keypoints_to_bearings_dev.argtypes = [C.POINTER(A.Camera), vp, vp, i, i, vp, i, vp]
     L.ovs_convert_keypoints_to_bearings.argtypes = [C.POINTER(A.Camera), A.kpp, i, A.f64p, i]
+    L.ovs_undistort_keypoints_dev.argtypes = [C.POINTER(A.Camera), vp, vp, i, i, vp, vp, i, vp]
+    L.ovs_undistort_keypoints.argtypes = [C.POINTER(A.Camera), A.kpp, i, A.kpp, i]
 
 
 def timing_report():

@@ -415,6 +415,32 @@ void convert_keypoints_to_bearings_equirectangular(const Camera& cam, const std:
                                             reinterpret_cast<double*>(bearings.data()), device));
 }
 
+// camera::perspective::undistort_keypoints (camera/perspective.cc:99-128): fx_, fy_, cx_, cy_, k1_, k2_, p1_, p2_, k3_
+template <class Camera, class KeyPoint>
+void undistort_keypoints_perspective(const Camera& cam, const std::vector<KeyPoint>& dist_keypts, std::vector<KeyPoint>& undist_keypts, int device = 0) {
+    static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout");
+    ovs_camera c{};
+    c.model = OVS_CAMERA_PERSPECTIVE;
+    c.fx = cam.fx_; c.fy = cam.fy_; c.cx = cam.cx_; c.cy = cam.cy_;
+    c.dist[0] = cam.k1_; c.dist[1] = cam.k2_; c.dist[2] = cam.p1_; c.dist[3] = cam.p2_; c.dist[4] = cam.k3_;
+    undist_keypts.resize(dist_keypts.size());
+    check(ovs_undistort_keypoints(&c, reinterpret_cast<const ovs_keypoint*>(dist_keypts.data()), static_cast<int>(dist_keypts.size()),
+                                  reinterpret_cast<ovs_keypoint*>(undist_keypts.data()), device));
+}
+
+// camera::fisheye::undistort_keypoints (camera/fisheye.cc:139-167): fx_, fy_, cx_, cy_, k1_, k2_, k3_, k4_
+template <class Camera, class KeyPoint>
+void undistort_keypoints_fisheye(const Camera& cam, const std::vector<KeyPoint>& dist_keypts, std::vector<KeyPoint>& undist_keypts, int device = 0) {
+    static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout");
+    ovs_camera c{};
+    c.model = OVS_CAMERA_FISHEYE;
+    c.fx = cam.fx_; c.fy = cam.fy_; c.cx = cam.cx_; c.cy = cam.cy_;
+    c.dist[0] = cam.k1_; c.dist[1] = cam.k2_; c.dist[2] = cam.k3_; c.dist[3] = cam.k4_;
+    undist_keypts.resize(dist_keypts.size());
+    check(ovs_undistort_keypoints(&c, reinterpret_cast<const ovs_keypoint*>(dist_keypts.data()), static_cast<int>(dist_keypts.size()),
+                                  reinterpret_cast<ovs_keypoint*>(undist_keypts.data()), device));
+}
+
 } // namespace camera
 
 namespace match {

@@ -210,6 +210,8 @@ int ovo_match_batch_current_and_last(const ovs_keypoint* kps, const uint8_t* des
 /* camera::*::convert_keypoints_to_bearings (camera/perspective.cc:130-138, fisheye.cc:169-177,
  * equirectangular.cc:45-56) */
 int ovo_convert_keypoints_to_bearings(const ovs_camera* cam, const ovs_keypoint* undist_keypts, int n, double* bearings);
+/* camera::*::undistort_keypoints (camera/perspective.cc:99-128, fisheye.cc:139-167, equirectangular.cc:41-43) */
+int ovo_undistort_keypoints(const ovs_camera* cam, const ovs_keypoint* dist_keypts, int n, ovs_keypoint* undist_keypts);
 
 #ifdef __cplusplus
 }

@@ -103,7 +103,7 @@ struct camera {
         return true;
     }
 };
-struct pinhole { double fx_ = 500, fy_ = 250, cx_ = 320, cy_ = 240; };
+struct pinhole { double fx_ = 500, fy_ = 250, cx_ = 320, cy_ = 240, k1_ = -0.2, k2_ = 0.05, p1_ = 0, p2_ = 0, k3_ = 0, k4_ = 0; };
 struct sphere { unsigned int cols_ = 640, rows_ = 320; };
 struct frame;
 
@@ -312,6 +312,14 @@ int main(int argc, char** argv) {
                        && bearings[1](0) == 1.0 / std::sqrt(2.0) && bearings[1](2) == 1.0 / std::sqrt(2.0);
     camera::convert_keypoints_to_bearings_equirectangular(mock::sphere{}, at_centre, bearings);
     bearings_ok = bearings_ok && std::fabs(bearings[2](0)) < 1e-15 && std::fabs(bearings[2](1)) < 1e-15 && std::fabs(bearings[2](2) - 1.0) < 1e-15;
+    // undistortion: the principal point stays, a point right of it moves outwards under barrel distortion (k1 < 0)
+    std::vector<mock::keypoint> undist;
+    at_centre[1].angle = 33.0f; at_centre[1].octave = 2; at_centre[1].size = 9.0f; at_centre[1].response = 50.0f;
+    camera::undistort_keypoints_perspective(mock::pinhole{}, at_centre, undist);
+    bearings_ok = bearings_ok && undist.size() == 3 && undist[0].x == 320.0f && undist[0].y == 240.0f && undist[1].x > 820.0f && undist[1].y == 240.0f
+                  && undist[1].angle == 33.0f && undist[1].octave == 2 && undist[1].size == 9.0f && undist[1].response == 0.0f && undist[1].class_id == -1;
+    camera::undistort_keypoints_fisheye(mock::pinhole{}, at_centre, undist);
+    bearings_ok = bearings_ok && undist.size() == 3 && undist[0].x == 320.0f && undist[0].y == 240.0f && undist[1].x > 820.0f;
     // stereo: frame 1 is frame 0 seen dx pixels to the left, i.e. a right camera image with disparity dx
     feature::orb_extractor ext_r(prm);
     std::vector<mock::keypoint> kps_r;

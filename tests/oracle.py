@@ -122,6 +122,7 @@ def _declare(L):
     L.ovo_match_batch_current_and_last.argtypes = [A.kpp, A.u8p, A.i32p, i, i, A.f32p, C.POINTER(A.Grid),
                                                    A.f32p, i, C.c_float, i, A.i32p, A.u32p]
     L.ovo_convert_keypoints_to_bearings.argtypes = [C.POINTER(A.Camera), A.kpp, i, A.f64p]
+    L.ovo_undistort_keypoints.argtypes = [C.POINTER(A.Camera), A.kpp, i, A.kpp]
 
 
 def check(rc):

@@ -57,7 +57,8 @@ def test_oracle_mirrors_the_compute_entry_points():
                "ovs_desc_db_search": "ovo_knn2_search",
                "ovs_desc_db_search_dev": "ovo_knn2_search", "ovs_knn2_merge_dev": "ovo_knn2_merge",
                "ovs_match_batch_current_and_last_dev": "ovo_match_batch_current_and_last",
-               "ovs_convert_keypoints_to_bearings_dev": "ovo_convert_keypoints_to_bearings"}
+               "ovs_convert_keypoints_to_bearings_dev": "ovo_convert_keypoints_to_bearings",
+               "ovs_undistort_keypoints_dev": "ovo_undistort_keypoints"}
     missing = []
     for n in declared():
         if n == "ovs_orb_get_num_keypts_per_level" or not not_compute.match(n):
