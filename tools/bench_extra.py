@@ -7,6 +7,7 @@ path at their full sizes, inputs resident in HBM, one JSON line each.
   knn      2000 queries against one shard of 1250 keyframes x 2000 descriptors      (distances/s)
   live     one frame at a time through the host-buffer entry points                  (ms per frame)
   pre      BGR -> gray, rectification remap, histogram stretch on 256 raw 1241x376 frames (frames/s)
+  post     keypoint undistortion + bearings of 256 frames x 2250 keypoints               (keypoints/s)
 """
 import argparse
 import ctypes as C
@@ -162,6 +163,44 @@ def pre(args):
             "ms_per_step": total_ms, "stages": out}
 
 
+def post(args):
+    """The step after the extractor on a resident batch: keypoint undistortion with the bearings
+    written by the same launch (28 B in, 28 + 24 B out per keypoint), per camera model."""
+    dev = torch.device("cuda", 0)
+    from openvslam_amd import camera
+    batch, cap, n_kp = 256, 2250, 2250
+    rng = np.random.default_rng(1)
+    kps = np.zeros(batch * cap, A.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 752, len(kps)).astype(np.float32)
+    kps["y"] = rng.uniform(0, 480, len(kps)).astype(np.float32)
+    d_in = torch.from_numpy(kps.view(np.uint8)).to(dev)
+    d_out = torch.zeros_like(d_in)
+    d_bear = torch.zeros((batch, cap, 3), dtype=torch.float64, device=dev)
+    cams = {"perspective (EuRoC, 20 iterations / 1e-6)": camera.perspective(458.654, 457.296, 367.215, 248.375, -0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0),
+            "fisheye (TUM-VI)": camera.fisheye(190.97847715128717, 190.9733070521226, 254.93170605935475, 256.8974428996504,
+                                               0.0034823894022493434, 0.0007150348452162257, -0.0020532361418706202, 0.00020293673591811182),
+            "equirectangular (copy + sin / cos)": camera.equirectangular(1920, 960)}
+    st = torch.cuda.current_stream(dev).cuda_stream
+    out = {}
+    reps = 50
+    for name, cam in cams.items():
+        def fn():
+            cam.undistort_keypoints_dev(d_in.data_ptr(), None, batch, cap, d_out.data_ptr(), d_bear.data_ptr(), st)
+        for _ in range(5):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[name] = {"ms": ms, "keypoints_per_s": batch * n_kp / (ms * 1e-3), "algorithmic_gbs": batch * n_kp * 80 / (ms * 1e-3) / 1e9}
+    first = next(iter(out.values()))
+    return {"metric": "keypoint undistortion + bearings, 256 frames x 2250 keypoints resident", "value": first["keypoints_per_s"], "unit": "keypoints/s",
+            "ms_per_step": first["ms"], "models": out}
+
+
 def live(args):
     """The live path: one frame at a time through the host-buffer entry points (image up, keypoints and
     descriptors down, synchronous), as the reference's tracking thread calls extract()."""
@@ -216,11 +255,11 @@ def live(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "live", "all"])
+    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "post", "live", "all"])
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    for name in (["stereo", "equirect", "knn", "pre", "live"] if args.workload == "all" else [args.workload]):
+    for name in (["stereo", "equirect", "knn", "pre", "post", "live"] if args.workload == "all" else [args.workload]):
         print(json.dumps(dict(workload=name, **globals()[name](args))))
 
 
