@@ -1680,11 +1680,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   * pattern: converted once per workgroup to fp32 in LDS (padded so a group's 16 lanes hit
 //     distinct banks); the rotation runs on packed fp32 (v_pk_mul_f32 / v_pk_add_f32 are plain
 //     IEEE multiplies and adds, so the reference's mul, mul, add order and rounding are kept),
-//     cvRound = v_cvt_i32_f32 (nearest even);
+//     cvRound = adding 1.5 * 2^23 (nearest even, the integer lands in the low mantissa bits);
 //   * descriptor bits are collected with sub + v_alignbit (sign bit shifted in), reversed once.
 constexpr int kPatchR = 18;                 // rows / columns -18 .. 18
 constexpr int kPatchRows = 2 * kPatchR + 1; // 37
-constexpr int kPatchDwords = 11;            // 44 bytes per row: 37 + up to 3 bytes of alignment
+constexpr int kPatchDwords = 12;            // 48 bytes per row: 37 + up to 3 bytes of alignment, fetched as three 16-byte parts
 constexpr int kPatchBytes = kPatchRows * kPatchDwords * 4;
 
 __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, const uint8_t* __restrict__ blur,
@@ -1771,13 +1771,18 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     const int first = (int)g.blur_off + (py - kPatchR) * step + px - kPatchR; // byte (-18, -18)
     const int first_al = first & ~3, sh = first & 3;
     u32* my_patch = reinterpret_cast<u32*>(&patch[grp][0]);
-    constexpr int kPatchLoads = (kPatchRows * kPatchDwords + kKpGroup - 1) / kKpGroup; // 26
-    u32 staged[kPatchLoads];
+    // A row is three 16-byte parts, a part is one lane's buffer_load_dwordx4 (the texture path
+    // spends its time per lane address, not per byte: 7 wide loads instead of 26 dword loads):
+    // slot 16 k + gl is part (slot % 3) of row (slot / 3), 111 slots, the last load has one spare lane.
+    constexpr int kPatchLoads = (3 * kPatchRows + kKpGroup - 1) / kKpGroup; // 7
+    static_assert(kPatchDwords == 12, "three 16-byte parts per row");
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 staged[kPatchLoads];
 #pragma unroll
-    for (int t = 0; t < kPatchLoads; ++t) {
-        const int i = t * kKpGroup + gl;
-        const int row = i / kPatchDwords, dw = i - row * kPatchDwords;
-        staged[t] = __builtin_amdgcn_raw_buffer_load_b32(bplane, first_al + __mul24(row, step) + 4 * dw, 0, 0); // past row 36: unused
+    for (int k = 0; k < kPatchLoads; ++k) {
+        const int slot = 16 * k + gl;
+        const int row = (slot * 171) >> 9; // slot / 3 for slot < 112
+        staged[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(bplane, first_al + __mul24(row, step) + 16 * (slot - 3 * row), 0, 0));
     }
 
     // ---- intensity centroid: m_10 = sum u * I, m_01 = sum v * I over the disc ----
@@ -1804,10 +1809,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     const float ca = trig_cos(arad), sa = trig_sin(arad);
 
 #pragma unroll
-    for (int t = 0; t < kPatchLoads; ++t) {
-        const int i = t * kKpGroup + gl;
-        if (i < kPatchRows * kPatchDwords) {
-            my_patch[i] = staged[t];
+    for (int k = 0; k < kPatchLoads; ++k) {
+        const int slot = 16 * k + gl;
+        if (slot < 3 * kPatchRows) {
+            reinterpret_cast<u32x4*>(my_patch)[slot] = staged[k]; // rows are 48 bytes: part `slot` sits at 16 * slot
         }
     }
     // the 16 lanes of a group are in one wavefront: their LDS writes are visible to each other
@@ -1817,19 +1822,28 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- rotated BRIEF on the staged neighbourhood ----
-    const uint8_t* centre = &patch[grp][0] + kPatchR * (kPatchDwords * 4) + kPatchR + sh;
+    // cvRound without a conversion: x + 1.5 * 2^23 rounds x to the nearest integer, ties to even,
+    // exactly as v_rndne / cvRound do (|x| < 2^22), and leaves it in the low mantissa bits:
+    // bits(x + M) = 0x4B400000 + round(x).  v_mul_i32_i24 reads bits 0..23 only, i.e.
+    // 0x400000 + round(x), so  row * 44 + col = mad24(bits_row, 44, bits_col) - kMagicBias  and the
+    // constant moves into the base address: one v_pk_add_f32 per sample point instead of two
+    // v_rndne + two v_cvt.
+    constexpr float kMagic = 12582912.0f;
+    constexpr int kMagicBias = 0x400000 * (kPatchDwords * 4) + 0x4B400000;
+    const uint8_t* centre = &patch[grp][0] + kPatchR * (kPatchDwords * 4) + kPatchR + sh - kMagicBias;
     const f32x2 sc = {sa, ca};  // (sin, cos)
     const f32x2 cs = {ca, -sa}; // (cos, -sin): y * (cos, -sin) added to x * (sin, cos) gives (row, col)
+    const f32x2 magic = {kMagic, kMagic};
     u32 bits = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const float4 pt = pat[gl * 17 + k];
         // row = x * sin + y * cos, col = x * cos - y * sin  (orb_extractor.cc:676-678); the
         // negated product y * (-sin) equals -(y * sin) exactly, so the subtraction is unchanged
-        const f32x2 rc0 = (f32x2){pt.x, pt.x} * sc + (f32x2){pt.y, pt.y} * cs;
-        const f32x2 rc1 = (f32x2){pt.z, pt.z} * sc + (f32x2){pt.w, pt.w} * cs;
-        const int v0 = centre[__mul24(__float2int_rn(rc0.x), kPatchDwords * 4) + __float2int_rn(rc0.y)];
-        const int v1 = centre[__mul24(__float2int_rn(rc1.x), kPatchDwords * 4) + __float2int_rn(rc1.y)];
+        const f32x2 rc0 = ((f32x2){pt.x, pt.x} * sc + (f32x2){pt.y, pt.y} * cs) + magic;
+        const f32x2 rc1 = ((f32x2){pt.z, pt.z} * sc + (f32x2){pt.w, pt.w} * cs) + magic;
+        const int v0 = centre[__mul24(__float_as_int(rc0.x), kPatchDwords * 4) + __float_as_int(rc0.y)];
+        const int v1 = centre[__mul24(__float_as_int(rc1.x), kPatchDwords * 4) + __float_as_int(rc1.y)];
         bits = __builtin_amdgcn_alignbit(bits, (u32)(v0 - v1), 31); // bits << 1 | (v0 < v1)
     }
     bits = __brev(bits) >> 16; // pair k of the lane at bit k
