@@ -1671,9 +1671,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 16 lanes per keypoint, 16 keypoints per workgroup.  Scattered byte reads from global memory cost
 // one cache-line lookup per lane, so both patches are fetched with row-contiguous dword loads:
-//   * moments: lane (h, q) = (g >> 3, g & 7) reads dword q of disc rows v = -15 + 2i + h; a
-//     per-row byte mask (LDS table indexed by |v|) cuts the dword to |u| <= u_max[|v|], then
-//     sum I and sum (u + 16) I are two v_dot4_u32_u8; integer sums, reduced across the group;
+//   * moments: a disc row is three 12-byte parts from the dword boundary left of it, one part per
+//     lane and load (six loads cover the 31 rows); byte masks from an LDS table indexed by |v|,
+//     the row's misalignment and the part cut the dwords to |u| <= u_max[|v|], then sum I and
+//     sum (window byte index) I are v_dot4_u32_u8 chains; integer sums, reduced across the group;
 //   * descriptor: the 37 x 37 neighbourhood of the blurred level (pattern radius 13 rotated:
 //     <= 18.4) goes to LDS as 37 rows of 11 aligned dwords; the 512 rotated sample reads are LDS
 //     byte reads.  Lane g owns pairs 16g .. 16g+15, i.e. bytes 2g and 2g+1 of the descriptor;
@@ -1693,7 +1694,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
                                                      ovs_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                      int* __restrict__ out_counts, int cap, int blocks_per_frame, int n_frames) {
     __shared__ float4 pat[16 * 17];   // (x0, y0, x1, y1) of pair 16 g + k at [17 g + k]
-    __shared__ u32 disc_mask[17][8];  // byte masks of a disc row by |v|; row 16 = empty
+    __shared__ __attribute__((aligned(16))) u32 disc_mask[17][4][3][4]; // byte masks of a 12-byte part of a disc row by |v| (16 = empty) and row misalignment
     __shared__ __attribute__((aligned(16))) uint8_t patch[16][kPatchBytes];
 
     const int blk = xcd_contiguous_block(blocks_per_frame * n_frames);
@@ -1731,18 +1732,22 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
         const int t = threadIdx.x;
         const int8_t* pp = &c_pattern[t * 4];
         pat[(t >> 4) * 17 + (t & 15)] = make_float4((float)pp[0], (float)pp[1], (float)pp[2], (float)pp[3]);
-        if (t < 17 * 8) {
-            const int av = t >> 3, q = t & 7;
-            u32 m = 0;
-            if (av <= kHalfPatch) {
-                const int d = c_umax[av];
+        if (t < 17 * 4 * 3) {
+            // window byte wb = 12 part + 4 d + b of a row whose first byte lies `mis` bytes left of
+            // u = -16 has u = wb - 16 - mis
+            const int av = t / 12, mis = (t - 12 * av) / 3, part = t - 12 * av - 3 * mis;
+            const int dmax = av <= kHalfPatch ? c_umax[av] : -1;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                u32 m = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int u = 4 * q + b - 16;
-                    m |= ((u < 0 ? -u : u) <= d) ? (0xFFu << (8 * b)) : 0u;
+                    const int u = 12 * part + 4 * d + b - 16 - mis;
+                    m |= ((u < 0 ? -u : u) <= dmax) ? (0xFFu << (8 * b)) : 0u;
                 }
+                disc_mask[av][mis][part][d] = m;
             }
-            disc_mask[av][q] = m;
+            disc_mask[av][mis][part][3] = 0;
         }
     }
     __syncthreads();
@@ -1786,20 +1791,31 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     }
 
     // ---- intensity centroid: m_10 = sum u * I, m_01 = sum v * I over the disc ----
+    // A disc row is the 31 bytes u = -15 .. 15; from the dword boundary at or below u = -16 that is
+    // at most 36 bytes = three 12-byte parts, each one lane's 12-byte load: 93 parts in six loads
+    // of the group's 16 lanes (the three spare slots read row 16 through an empty mask).
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    const int hq = gl >> 3, q = gl & 7;
-    const u32 wts = 0x03020100u + 0x04040404u * (u32)q; // u + 16 of the dword's four bytes
-    const uint8_t* col = img + (long long)py * pitch + px - 16 + 4 * q;
+    typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const uint8_t* win = img + (long long)py * pitch + (px - 16); // (v, u) = (0, -16)
     int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int v = -kHalfPatch + 2 * i + hq; // 16 for the odd half of the last step: empty mask row
+    for (int k = 0; k < 6; ++k) {
+        const int slot = 16 * k + gl;
+        const int ri = (slot * 171) >> 9; // slot / 3
+        const int part = slot - 3 * ri;
+        const int v = ri - kHalfPatch;    // 16 in the spare slots
         const int av = v < 0 ? -v : v;
-        const u32 w = load_u32_unaligned(col + (long long)v * pitch) & disc_mask[av][q];
-        const int s0 = (int)__builtin_amdgcn_udot4(w, 0x01010101u, 0u, false);
-        const int s1 = (int)__builtin_amdgcn_udot4(w, wts, 0u, false);
-        m10 += s1 - 16 * s0;
+        const uint8_t* rowp = win + (long long)v * pitch;
+        const u32 mis = (u32)reinterpret_cast<uintptr_t>(rowp) & 3u;
+        const u32x3_a4 w = *reinterpret_cast<const u32x3_a4*>(rowp - mis + 12 * part);
+        const u32x4 mk = *reinterpret_cast<const u32x4*>(&disc_mask[av][mis][part][0]);
+        const u32 w0 = w.x & mk.x, w1 = w.y & mk.y, w2 = w.z & mk.z;
+        const u32 wt0 = 0x03020100u + 0x04040404u * (u32)(3 * part); // window byte index of the part's bytes
+        const int s0 = (int)__builtin_amdgcn_udot4(w0, 0x01010101u, __builtin_amdgcn_udot4(w1, 0x01010101u, __builtin_amdgcn_udot4(w2, 0x01010101u, 0u, false), false), false);
+        const int s1 = (int)__builtin_amdgcn_udot4(w0, wt0, __builtin_amdgcn_udot4(w1, wt0 + 0x04040404u, __builtin_amdgcn_udot4(w2, wt0 + 0x08080808u, 0u, false), false), false);
+        m10 += s1 - (16 + (int)mis) * s0; // u = window byte index - 16 - mis
         m01 += v * s0;
     }
     m10 = group_sum_i32<kKpGroup>(m10);
