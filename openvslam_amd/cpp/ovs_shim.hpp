@@ -41,7 +41,8 @@ inline void check(int rc) {
 }
 
 // Adapter between the caller's 8-bit matrix type and raw memory.  Specialise for cv::Mat in the
-// reference tree (INTEGRATION.md shows the ten lines); the primary template fits any type with
+// reference tree (empty / data / cols / rows / step / create_u8 / release over the cv::Mat members
+// of the same meaning, about ten lines); the primary template fits any type with
 // data / cols / rows / step members and create(rows, cols).
 template <class Mat>
 struct mat_traits {
