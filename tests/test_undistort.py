@@ -263,3 +263,34 @@ def test_gpu_batch_with_bearings_in_the_same_launch(with_counts):
         assert got[f, :n].tobytes() == want[f, :n].tobytes(), f
         assert np.array_equal(got_b[f, :n].view(np.uint64), want_b[f, :n].view(np.uint64)), f
         assert np.all(got[f, n:].view(np.uint8) == 0xAB) and np.all(got_b[f, n:] == -7.0), f
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_batch_properties():
+    """256 frames x 2250 keypoints (the extractor's batch): properties that need no oracle run --
+    bearings have unit length, pushing the undistorted points through the forward model returns
+    the input -- plus an oracle comparison of a 5000-keypoint sample."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_frames, cap = 256, 2250
+    rng = np.random.default_rng(12)
+    kps = keypoints(rng, n_frames * cap, EUROC["cols"], EUROC["rows"])
+    cam = make_camera("perspective", EUROC)
+    d_kps = torch.from_numpy(kps.view(np.uint8)).to(dev)
+    d_out = torch.zeros_like(d_kps)
+    d_bear = torch.zeros((n_frames * cap, 3), dtype=torch.float64, device=dev)
+    cam.undistort_keypoints_dev(d_kps.data_ptr(), None, n_frames, cap, d_out.data_ptr(), d_bear.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    got = d_out.cpu().numpy().view(A.KEYPOINT_DTYPE)
+    bear = d_bear.cpu().numpy()
+    assert np.max(np.abs(np.linalg.norm(bear, axis=1) - 1.0)) < 1e-15
+    xn = (got["x"].astype(np.float64) - f32(EUROC["cx"])) / f32(EUROC["fx"])
+    yn = (got["y"].astype(np.float64) - f32(EUROC["cy"])) / f32(EUROC["fy"])
+    u, v = distort_perspective(xn, yn, EUROC)
+    assert np.max(np.abs(u - kps["x"])) < 2e-3 and np.max(np.abs(v - kps["y"])) < 2e-3
+    # the bearing is the normalised (x_n, y_n, 1) of the undistorted point (unnarrowed camera parameters)
+    xb = (got["x"].astype(np.float64) - EUROC["cx"]) / EUROC["fx"]
+    assert np.allclose(bear[:, 0] / bear[:, 2], xb, rtol=0, atol=1e-14)
+    pick = rng.choice(len(kps), 5000, replace=False)
+    sample = np.ascontiguousarray(kps[pick])
+    assert got[pick].tobytes() == oracle_undistort(cam._cam, sample).tobytes()
