@@ -374,8 +374,13 @@ int ovs_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
                             float lowe_ratio, int check_orientation,
                             int32_t* matched_idx2_in_kf1, uint32_t* num_matches, int device);
 
-/* robust::match_for_triangulation (src/openvslam/match/robust.cc:18-172).  The epipolar gates
- * are evaluated in double exactly as robust.cc:106-121,317-335:
+/* robust::match_for_triangulation (src/openvslam/match/robust.cc:18-172).  Distances, the epipole
+ * gate (robust.cc:106-116), the epipolar residual gate (robust.cc:317-335) and the sequential
+ * "already matched" rule run on the device, the gates in double.  The residual gate compares
+ * cosines (asin(c) < T  <=>  c < sin T); a pair whose cosine lies within 1e-13 of the threshold is
+ * re-evaluated on the host with the reference's expression (acos of the host libm) and, should the
+ * two disagree, the match is repeated with that decision, so the result is the reference's.
+ * Every keypoint index appears in at most one node of its feature vector (as in DBoW2).
  *   bearings_1/2     n x 3 doubles; E_12 row-major 3x3; epipole_in_2 = reproject_to_bearing of
  *                    camera centre 1 into keyframe 2 (robust.cc:25-29)
  *   has_lm_1/2       assoc landmark non-null (those keypoints are skipped, robust.cc:64,83)
@@ -459,9 +464,9 @@ int ovs_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_querie
  *   frm_2                       the frame searched; its grid is queried with (margin, level 0..0)
  *   prev_matched_pts            n1 x 2 floats, in/out: search centres, updated for matched keypoints
  *   matched_indices_2_in_frm_1  out, n1 ints (-1 = none);  *num_matches = the return value
- * The window queries and all Hamming distances run on the device; the overwrite rule of
- * area.cc:46-49,75-85 (a later keypoint takes over a candidate it is strictly closer to) is a
- * sequential pass over those distances on the host. */
+ * Window queries, Hamming distances and the overwrite rule of area.cc:46-49,75-85 (a later keypoint
+ * takes over a candidate it is strictly closer to) run on the device; frm_2 may hold at most about
+ * 18 000 keypoints (its per-keypoint state lives in LDS), more give OVS_ERR_UNSUPPORTED. */
 int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
                                  const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
                                  float lowe_ratio, int check_orientation,

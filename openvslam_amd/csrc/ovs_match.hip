@@ -5,7 +5,6 @@
 // None of this is a dense contraction, so there is no MFMA here: distances are v_xor + v_bcnt over
 // 8 dwords, selections are per-lane running minima merged by the lexicographic (distance, row) key.
 #include "ovs_match_common.h"
-#include "std_sort_port.h"
 
 #include <algorithm>
 #include <cmath>
@@ -726,339 +725,6 @@ int ovs_knn2_merge(const ovs_knn2* lists, int n_lists, int nq, ovs_knn2* out) {
         r.row[1] = m1 == kNoKey ? -1 : static_cast<long long>(m1 & 0xFFFFFFFFFFFFull);
         out[qi] = r;
     }
-    return OVS_OK;
-}
-
-int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
-                                const ovs_keypoint* undist_keypts_1, const double* bearings_1,
-                                const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,
-                                const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2,
-                                const ovs_keypoint* undist_keypts_2, const double* bearings_2,
-                                const float* stereo_x_right_2, const uint8_t* has_lm_2, int n2,
-                                const double* E_12, const double* epipole_in_2,
-                                const float* scale_factors_1, int num_scale_levels_1,
-                                int check_orientation,
-                                uint32_t* pairs, uint32_t* num_matches, int device) {
-    // robust::match_for_triangulation (robust.cc:18-172).  The Hamming distances of all bucket
-    // pairs are computed on the device in one launch; the selection loop with its double-precision
-    // epipolar gates (std::acos, robust.cc:317-335) runs on the host in the reference's order, so
-    // the gates use the very libm calls the reference uses.
-    if (!vec_1 || !vec_2 || n1 < 0 || n2 < 0 || !E_12 || !epipole_in_2 || !scale_factors_1 || !pairs || !num_matches
-        || (n1 > 0 && (!descs_1 || !undist_keypts_1 || !bearings_1)) || (n2 > 0 && (!descs_2 || !undist_keypts_2 || !bearings_2))) {
-        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
-    }
-    int rc = check_device(device);
-    if (rc != OVS_OK) {
-        return rc;
-    }
-    // 1. enumerate the (idx_1, idx_2) pairs of the merge-join in loop order
-    struct bucket {
-        u32 a_lo, a_hi, b_lo, b_hi;
-        size_t pair_base;
-    };
-    std::vector<bucket> buckets;
-    std::vector<u32> pa, pb;
-    {
-        int a = 0, b = 0;
-        while (a != vec_1->num_nodes && b != vec_2->num_nodes) {
-            if (vec_1->node_ids[a] == vec_2->node_ids[b]) {
-                bucket bk{vec_1->offsets[a], vec_1->offsets[a + 1], vec_2->offsets[b], vec_2->offsets[b + 1], pa.size()};
-                for (u32 x = bk.a_lo; x < bk.a_hi; ++x) {
-                    if (static_cast<int>(vec_1->indices[x]) >= n1) {
-                        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
-                    }
-                    for (u32 y = bk.b_lo; y < bk.b_hi; ++y) {
-                        if (static_cast<int>(vec_2->indices[y]) >= n2) {
-                            return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
-                        }
-                        pa.push_back(vec_1->indices[x]);
-                        pb.push_back(vec_2->indices[y]);
-                    }
-                }
-                buckets.push_back(bk);
-                ++a;
-                ++b;
-            }
-            else if (vec_1->node_ids[a] < vec_2->node_ids[b]) {
-                a = static_cast<int>(std::lower_bound(vec_1->node_ids, vec_1->node_ids + vec_1->num_nodes, vec_2->node_ids[b]) - vec_1->node_ids);
-            }
-            else {
-                b = static_cast<int>(std::lower_bound(vec_2->node_ids, vec_2->node_ids + vec_2->num_nodes, vec_1->node_ids[a]) - vec_2->node_ids);
-            }
-        }
-    }
-    // 2. distances on the device
-    const size_t np = pa.size();
-    std::vector<unsigned short> dist(np);
-    if (np) {
-        ovs::device_guard guard(device);
-        thread_ctx* ctx = ctx_for(device);
-        if ((rc = ensure_stream(ctx)) != OVS_OK) return rc;
-        const size_t s1 = n1, s2 = n2;
-        if ((rc = ctx->arena.reserve(al(s1 * 32) + al(s2 * 32) + 2 * al(np * 4) + al(np * 2))) != OVS_OK) return rc;
-        carver cv;
-        cv.base = ctx->arena.as<uint8_t>();
-        auto* d1 = cv.take<uint8_t>(s1 * 32);
-        auto* d2 = cv.take<uint8_t>(s2 * 32);
-        auto* da = cv.take<u32>(np);
-        auto* db = cv.take<u32>(np);
-        auto* dd = cv.take<unsigned short>(np);
-        OVS_HIP(hipMemcpyAsync(d1, descs_1, s1 * 32, hipMemcpyHostToDevice, ctx->stream));
-        OVS_HIP(hipMemcpyAsync(d2, descs_2, s2 * 32, hipMemcpyHostToDevice, ctx->stream));
-        OVS_HIP(hipMemcpyAsync(da, pa.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
-        OVS_HIP(hipMemcpyAsync(db, pb.data(), np * 4, hipMemcpyHostToDevice, ctx->stream));
-        OVS_LAUNCH("k_hamming_indexed", k_hamming_indexed, dim3((np + 255) / 256), dim3(256), 0, ctx->stream, d1, da, d2, db, static_cast<long long>(np), dd);
-        OVS_HIP(hipMemcpyAsync(dist.data(), dd, np * 2, hipMemcpyDeviceToHost, ctx->stream));
-        OVS_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    // 3. the reference's selection loop over the precomputed distances
-    unsigned int num = 0;
-    std::vector<bool> is_already_matched_in_keyfrm_2(n2, false);
-    std::vector<int> matched_indices_2_in_keyfrm_1(n1, -1);
-    std::vector<std::pair<float, int>> angle_entries; // (delta angle, idx_1) in append order
-    auto check_epipolar_constraint = [&](const double* bearing_1, const double* bearing_2, float bearing_1_scale_factor) {
-        double e[3];
-        for (int r = 0; r < 3; ++r) {
-            e[r] = E_12[3 * r] * bearing_2[0] + E_12[3 * r + 1] * bearing_2[1] + E_12[3 * r + 2] * bearing_2[2];
-        }
-        const double dot = e[0] * bearing_1[0] + e[1] * bearing_1[1] + e[2] * bearing_1[2];
-        const double norm = std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
-        const double cos_residual = dot / norm;
-        const double residual_rad = M_PI / 2.0 - std::abs(std::acos(cos_residual));
-        constexpr double residual_rad_thr = 0.2 * M_PI / 180.0;
-        return residual_rad < residual_rad_thr * bearing_1_scale_factor;
-    };
-    for (const bucket& bk : buckets) {
-        const size_t nb = bk.b_hi - bk.b_lo;
-        for (u32 x = bk.a_lo; x < bk.a_hi; ++x) {
-            const u32 idx_1 = vec_1->indices[x];
-            if (has_lm_1 && has_lm_1[idx_1]) {
-                continue;
-            }
-            const bool is_stereo_keypt_1 = 0 <= (stereo_x_right_1 ? stereo_x_right_1[idx_1] : -1.0f);
-            const ovs_keypoint& keypt_1 = undist_keypts_1[idx_1];
-            if (keypt_1.octave < 0 || num_scale_levels_1 <= keypt_1.octave) {
-                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "octave out of range");
-            }
-            const double* bearing_1 = bearings_1 + 3 * static_cast<size_t>(idx_1);
-            unsigned int best_hamm_dist = kThrLow;
-            int best_idx_2 = -1;
-            for (u32 y = bk.b_lo; y < bk.b_hi; ++y) {
-                const u32 idx_2 = vec_2->indices[y];
-                if (has_lm_2 && has_lm_2[idx_2]) {
-                    continue;
-                }
-                if (is_already_matched_in_keyfrm_2[idx_2]) {
-                    continue;
-                }
-                const bool is_stereo_keypt_2 = 0 <= (stereo_x_right_2 ? stereo_x_right_2[idx_2] : -1.0f);
-                const double* bearing_2 = bearings_2 + 3 * static_cast<size_t>(idx_2);
-                const unsigned int hamm_dist = dist[bk.pair_base + static_cast<size_t>(x - bk.a_lo) * nb + (y - bk.b_lo)];
-                if (kThrLow < hamm_dist || best_hamm_dist < hamm_dist) {
-                    continue;
-                }
-                if (!is_stereo_keypt_1 && !is_stereo_keypt_2) {
-                    const double cos_dist = epipole_in_2[0] * bearing_2[0] + epipole_in_2[1] * bearing_2[1] + epipole_in_2[2] * bearing_2[2];
-                    constexpr double cos_dist_thr = 0.99862953475;
-                    if (cos_dist_thr < cos_dist) {
-                        continue;
-                    }
-                }
-                if (check_epipolar_constraint(bearing_1, bearing_2, scale_factors_1[keypt_1.octave])) {
-                    best_idx_2 = static_cast<int>(idx_2);
-                    best_hamm_dist = hamm_dist;
-                }
-            }
-            if (best_idx_2 < 0) {
-                continue;
-            }
-            is_already_matched_in_keyfrm_2[best_idx_2] = true;
-            matched_indices_2_in_keyfrm_1[idx_1] = best_idx_2;
-            ++num;
-            if (check_orientation) {
-                angle_entries.emplace_back(keypt_1.angle - undist_keypts_2[best_idx_2].angle, static_cast<int>(idx_1));
-            }
-        }
-    }
-    if (check_orientation) {
-        // match::angle_checker (angle_checker.h:72-134): 30 bins, the three fullest stay
-        unsigned hist[30] = {0};
-        std::vector<int> bins(angle_entries.size());
-        for (size_t i = 0; i < angle_entries.size(); ++i) {
-            float delta_angle = angle_entries[i].first;
-            if (delta_angle < 0.0) {
-                delta_angle += 360.0;
-            }
-            if (360.0 <= delta_angle) {
-                delta_angle -= 360.0;
-            }
-            const int bin = static_cast<int>(lrintf(delta_angle * (1.0f / 30)));
-            if (bin < 0 || 30 <= bin) {
-                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "rotation bin out of range");
-            }
-            bins[i] = bin;
-            ++hist[bin];
-        }
-        unsigned order[30];
-        ovs_sort::index_sort_by_size(hist, order, 30);
-        for (size_t i = 0; i < angle_entries.size(); ++i) {
-            const unsigned bin = static_cast<unsigned>(bins[i]);
-            if (bin != order[0] && bin != order[1] && bin != order[2]) {
-                matched_indices_2_in_keyfrm_1[angle_entries[i].second] = -1;
-                --num;
-            }
-        }
-    }
-    unsigned k = 0;
-    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
-        if (matched_indices_2_in_keyfrm_1[idx_1] < 0) {
-            continue;
-        }
-        pairs[2 * k] = static_cast<uint32_t>(idx_1);
-        pairs[2 * k + 1] = static_cast<uint32_t>(matched_indices_2_in_keyfrm_1[idx_1]);
-        ++k;
-    }
-    *num_matches = num;
-    return OVS_OK;
-}
-
-int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
-                                 const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
-                                 float lowe_ratio, int check_orientation,
-                                 int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches, int device) {
-    if (n1 < 0 || !frm_2 || !num_matches || (n1 > 0 && (!undist_keypts_1 || !descs_1 || !prev_matched_pts || !matched_indices_2_in_frm_1))) {
-        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
-    }
-    const int n2 = frm_2->num_keypts;
-    std::fill(matched_indices_2_in_frm_1, matched_indices_2_in_frm_1 + n1, -1);
-    *num_matches = 0;
-    // 1. windows of the octave-0 keypoints of frame 1 in frame 2 (device), reference order
-    std::vector<int> qidx;
-    std::vector<float> ref_xy, margins;
-    std::vector<int32_t> lv;
-    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
-        if (0 < undist_keypts_1[idx_1].octave) {
-            continue; // area.cc:24-26
-        }
-        qidx.push_back(idx_1);
-        ref_xy.push_back(prev_matched_pts[2 * idx_1]);
-        ref_xy.push_back(prev_matched_pts[2 * idx_1 + 1]);
-        margins.push_back(static_cast<float>(margin));
-        lv.push_back(undist_keypts_1[idx_1].octave); // min_level = max_level = scale_level_1, area.cc:29-30
-    }
-    const int nq = static_cast<int>(qidx.size());
-    if (nq == 0 || n2 == 0) {
-        return OVS_OK;
-    }
-    std::vector<uint32_t> offsets(static_cast<size_t>(nq) + 1), indices(static_cast<size_t>(nq) * 32 + 1024);
-    int rc = ovs_get_keypoints_in_cell(frm_2, nq, ref_xy.data(), margins.data(), lv.data(), lv.data(), indices.data(),
-                                       static_cast<int>(indices.size()), offsets.data(), device);
-    if (rc == OVS_ERR_CAPACITY) {
-        indices.resize(offsets[nq]);
-        rc = ovs_get_keypoints_in_cell(frm_2, nq, ref_xy.data(), margins.data(), lv.data(), lv.data(), indices.data(),
-                                       static_cast<int>(indices.size()), offsets.data(), device);
-    }
-    if (rc != OVS_OK) {
-        return rc;
-    }
-    // 2. all (keypoint, candidate) distances on the device
-    const size_t np = offsets[nq];
-    std::vector<uint32_t> dist(np);
-    if (np) {
-        std::vector<uint8_t> a(np * 32), b(np * 32);
-        for (int q = 0; q < nq; ++q) {
-            for (uint32_t e = offsets[q]; e < offsets[q + 1]; ++e) {
-                std::memcpy(&a[32 * static_cast<size_t>(e)], descs_1 + 32 * static_cast<size_t>(qidx[q]), 32);
-                std::memcpy(&b[32 * static_cast<size_t>(e)], frm_2->descriptors + 32 * static_cast<size_t>(indices[e]), 32);
-            }
-        }
-        if (np > 0x7FFFFFFFu) {
-            return ovs::fail(OVS_ERR_UNSUPPORTED, "too many candidate pairs");
-        }
-        if ((rc = ovs_hamming_pairs(a.data(), b.data(), static_cast<int>(np), dist.data(), device)) != OVS_OK) {
-            return rc;
-        }
-    }
-    // 3. the reference's sequential pass (area.cc:19-92) over the precomputed distances
-    unsigned int num = 0;
-    std::vector<unsigned int> matched_dists_in_frm_2(n2, kMaxDist);
-    std::vector<int> matched_indices_1_in_frm_2(n2, -1);
-    std::vector<std::pair<float, int>> angle_entries;
-    for (int q = 0; q < nq; ++q) {
-        const int idx_1 = qidx[q];
-        unsigned int best_hamm_dist = kMaxDist, second_best_hamm_dist = kMaxDist;
-        int best_idx_2 = -1;
-        for (uint32_t e = offsets[q]; e < offsets[q + 1]; ++e) {
-            const uint32_t idx_2 = indices[e];
-            const unsigned int hamm_dist = dist[e];
-            if (matched_dists_in_frm_2[idx_2] <= hamm_dist) {
-                continue;
-            }
-            if (hamm_dist < best_hamm_dist) {
-                second_best_hamm_dist = best_hamm_dist;
-                best_hamm_dist = hamm_dist;
-                best_idx_2 = static_cast<int>(idx_2);
-            }
-            else if (hamm_dist < second_best_hamm_dist) {
-                second_best_hamm_dist = hamm_dist;
-            }
-        }
-        if (kThrLow < best_hamm_dist) {
-            continue;
-        }
-        if (second_best_hamm_dist * lowe_ratio < static_cast<float>(best_hamm_dist)) {
-            continue;
-        }
-        const int prev_idx_1 = matched_indices_1_in_frm_2[best_idx_2];
-        if (0 <= prev_idx_1) {
-            matched_indices_2_in_frm_1[prev_idx_1] = -1;
-            --num;
-        }
-        matched_indices_2_in_frm_1[idx_1] = best_idx_2;
-        matched_indices_1_in_frm_2[best_idx_2] = idx_1;
-        matched_dists_in_frm_2[best_idx_2] = best_hamm_dist;
-        ++num;
-        if (check_orientation) {
-            angle_entries.emplace_back(undist_keypts_1[idx_1].angle - frm_2->undist_keypts[best_idx_2].angle, idx_1);
-        }
-    }
-    if (check_orientation) {
-        // match::angle_checker (angle_checker.h:72-134): 30 bins, the three fullest stay
-        unsigned hist[30] = {0};
-        std::vector<int> bins(angle_entries.size());
-        for (size_t i = 0; i < angle_entries.size(); ++i) {
-            float delta_angle = angle_entries[i].first;
-            if (delta_angle < 0.0) {
-                delta_angle += 360.0;
-            }
-            if (360.0 <= delta_angle) {
-                delta_angle -= 360.0;
-            }
-            const int bin = static_cast<int>(lrintf(delta_angle * (1.0f / 30)));
-            if (bin < 0 || 30 <= bin) {
-                return ovs::fail(OVS_ERR_OUT_OF_RANGE, "rotation bin out of range");
-            }
-            bins[i] = bin;
-            ++hist[bin];
-        }
-        unsigned order[30];
-        ovs_sort::index_sort_by_size(hist, order, 30);
-        for (size_t i = 0; i < angle_entries.size(); ++i) {
-            const unsigned bin = static_cast<unsigned>(bins[i]);
-            if (bin != order[0] && bin != order[1] && bin != order[2] && 0 <= matched_indices_2_in_frm_1[angle_entries[i].second]) {
-                matched_indices_2_in_frm_1[angle_entries[i].second] = -1;
-                --num;
-            }
-        }
-    }
-    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
-        if (0 <= matched_indices_2_in_frm_1[idx_1]) {
-            const ovs_keypoint& kp = frm_2->undist_keypts[matched_indices_2_in_frm_1[idx_1]];
-            prev_matched_pts[2 * idx_1] = kp.x;
-            prev_matched_pts[2 * idx_1 + 1] = kp.y;
-        }
-    }
-    *num_matches = num;
     return OVS_OK;
 }
 

@@ -21,7 +21,12 @@
 #include "std_sort_port.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <mutex>
+#include <set>
+#include <utility>
+#include <vector>
 
 using namespace ovsm;
 
@@ -39,7 +44,17 @@ enum proj_kind {
     kRange = 5,       // robust::brute_force_match / bow_tree::match_*: every query names one contiguous
                       // range of the candidate list; best <= 50 and Lowe's ratio against the runner-up
     kFuseDetect = 6,  // fuse::detect_duplication: per query best keypoint, signed level gate, <= 50
-    kFuseReplace = 7  // fuse::replace_duplication: unsigned level gate + chi-square reprojection gate
+    kFuseReplace = 7, // fuse::replace_duplication: unsigned level gate + chi-square reprojection gate
+    kArea = 8,        // area::match_in_consistent_area: level-0 window, ratio test, a strictly closer query takes a keypoint over
+    kTri = 9          // robust::match_for_triangulation: bucket ranges, epipole / epipolar gates in double, last of equals wins
+};
+
+// what is compiled into an instance of the candidate / resolve kernels besides the tracking matchers
+enum proj_mode {
+    kModePlain = 0,
+    kModeFuse = 1, // the double-precision chi-square gate of match::fuse
+    kModeTri = 2,  // the double-precision epipolar gates of robust::match_for_triangulation
+    kModeArea = 3  // per-keypoint (distance, owner) state instead of the claim bitmap
 };
 
 __host__ __device__ inline bool kind_is_one_way(int kind) { return kind == kOneWay || kind == kFuseDetect || kind == kFuseReplace; }
@@ -56,6 +71,12 @@ struct frame_dev {
     const uint4* g_entry;  // grid order: {x bits, y bits, octave, keypoint index}
     const uint4* g_desc;   // grid order: two uint4 per keypoint
     const float* inv_level_sigma_sq; // kFuseReplace only
+    // kTri only
+    const double* bearings; // n x 3: bearings_ of the searched keyframe
+    const double* tri_E;    // E_12 row-major (9) followed by the epipole in the searched keyframe (3)
+    u32* tri_amb;           // [0] = number of borderline pairs seen, [1] = capacity, then (query, entry) pairs
+    const u32* tri_ovr;     // [0] = number of pairs, then (query, entry) pairs whose epipolar decision is the
+                            // opposite of the device's comparison (established on the host, see run_triangulation)
 };
 
 struct query_dev {
@@ -70,6 +91,9 @@ struct query_dev {
     const u32* range_lo; // kRange: candidates of query i are entries [range_lo[i], range_hi[i])
     const u32* range_hi;
     const double* reproj_xy_d; // kFuseReplace: the double-precision reprojection of the chi-square gate
+    const double* bearings;    // kTri: n x 3 bearings of the query keypoints
+    const double* sin_thr;     // kTri: n, sine of the epipolar residual threshold of the query's scale level
+    const uint8_t* stereo;     // kTri: n, 1 = the query keypoint has a stereo x_right >= 0
 };
 
 struct proj_params {
@@ -246,17 +270,24 @@ struct query_ctx {
     u32 lo, hi;
     int fuse;       // 0: none, 1: signed level gate (fuse.cc:86), 2: unsigned gate + chi-square gate (fuse.cc:194-222)
     double rxd, ryd;
+    // kTri: bearing of the query keypoint, sine of its residual threshold, stereo flag, query number
+    double b1x, b1y, b1z, sin_thr;
+    bool stereo1;
+    int qi;
 };
 
-// FUSE: the two match::fuse kinds are compiled in (separate kernel instances keep their double-
-// precision state and gates out of the tracking matchers' kernels)
-template <bool FUSE>
+// MODE: what besides the tracking matchers is compiled in (separate kernel instances keep the double-
+// precision state and gates of match::fuse and of the triangulation matcher out of their kernels)
+template <int MODE>
 __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const frame_dev& f, const query_dev& q, int qi, query_ctx& c) {
     c.ranged = false;
     c.lo = c.hi = 0;
     c.fuse = 0;
     c.rxd = c.ryd = 0.0;
-    if (pp.kind == kRange) {
+    c.b1x = c.b1y = c.b1z = c.sin_thr = 0.0;
+    c.stereo1 = false;
+    c.qi = qi;
+    if (pp.kind == kRange || pp.kind == kTri) {
         c.ranged = true;
         c.lo = q.range_lo[qi];
         c.hi = q.range_hi[qi];
@@ -265,9 +296,29 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
         c.ugate = false;
         c.sl = 0;
         c.stereo_gate = false;
+        if (MODE == kModeTri) {
+            c.b1x = q.bearings[3 * (size_t)qi];
+            c.b1y = q.bearings[3 * (size_t)qi + 1];
+            c.b1z = q.bearings[3 * (size_t)qi + 2];
+            c.sin_thr = q.sin_thr[qi];
+            c.stereo1 = q.stereo[qi] != 0;
+        }
         return true;
     }
     const int sl = q.scale_level[qi];
+    if (pp.kind == kArea) {
+        // get_keypoints_in_cell(x, y, margin, scale_level_1, scale_level_1), area.cc:29-30: the margin is
+        // not scaled, and a negative level switches the level gate off (common.cc:154)
+        c.rx = q.reproj_xy[2 * qi];
+        c.ry = q.reproj_xy[2 * qi + 1];
+        c.margin = pp.margin;
+        c.xr = -1.0f;
+        c.sl = 0;
+        c.ugate = false;
+        c.stereo_gate = false;
+        c.min_level = c.max_level = sl;
+        return true;
+    }
     if (sl < 0 || f.num_levels <= sl) {
         return false;
     }
@@ -306,7 +357,7 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
         case kFuseDetect:
             c.min_level = -1;
             c.max_level = -1;
-            if (FUSE) {
+            if (MODE == kModeFuse) {
                 c.fuse = 1;
             }
             break;
@@ -314,7 +365,7 @@ __device__ __forceinline__ bool make_query_ctx(const proj_params& pp, const fram
             c.min_level = -1;
             c.max_level = -1;
             c.ugate = true;
-            if (FUSE) {
+            if (MODE == kModeFuse) {
                 c.fuse = 2;
                 c.rxd = q.reproj_xy_d[2 * qi];
                 c.ryd = q.reproj_xy_d[2 * qi + 1];
@@ -339,7 +390,7 @@ __device__ __forceinline__ u32 key_idx(u64 k) { return (u32)(k & 0xFFFFFu); }
 
 // window / level gates of get_keypoints_in_cell (common.cc:166-178) + the per-candidate gates of
 // the projection loops that do not depend on earlier queries
-template <bool FUSE>
+template <int MODE>
 __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx& c, const uint4& en, const uint8_t* occupied, const u32* blocked,
                                              bool matcher_gates) {
     if (c.ranged) {
@@ -349,6 +400,8 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
         }
         return !(blocked && ((blocked[ridx >> 5] >> (ridx & 31)) & 1u));
     }
+    // kModeArea: `blocked` is the per-keypoint (distance, owner) state, tested against the distance in
+    // window_topk
     const int oct = (int)en.z;
     const bool check_level = (0 < c.min_level) || (0 <= c.max_level);
     if (check_level) {
@@ -371,7 +424,7 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
     if (occupied && occupied[idx]) {
         return false;
     }
-    if (blocked && ((blocked[idx >> 5] >> (idx & 31)) & 1u)) {
+    if (MODE != kModeArea && blocked && ((blocked[idx >> 5] >> (idx & 31)) & 1u)) {
         return false;
     }
     if (c.ugate) {
@@ -389,13 +442,13 @@ __device__ __forceinline__ bool passes_gates(const frame_dev& f, const query_ctx
             }
         }
     }
-    if (FUSE && c.fuse == 1) {
+    if (MODE == kModeFuse && c.fuse == 1) {
         // int scale_level, int pred_scale_level (fuse.cc:68,83-88)
         if (oct < (int)c.sl - 1 || (int)c.sl < oct) {
             return false;
         }
     }
-    else if (FUSE && c.fuse == 2) {
+    else if (MODE == kModeFuse && c.fuse == 2) {
         // fuse.cc:198-222: reproj is double, keypoint and x_right are float; products and sums in the
         // reference's order without contraction
         const double e_x = __dsub_rn(c.rxd, (double)__uint_as_float(en.x));
@@ -428,11 +481,65 @@ constexpr u32 kNoKey32 = 0xFFFFFFFFu;
 __device__ __forceinline__ u32 sel_dist(u32 k) { return k >> 20; }
 __device__ __forceinline__ u32 sel_entry(u32 k) { return k & 0xFFFFFu; }
 // the list format of the resolve kernel: distance, tie-break position, keypoint index
+// (the triangulation matcher keeps the LAST of equally distant candidates, robust.cc:102: its keys carry
+// the entry index complemented, so that the smallest key is again the winner)
+template <int MODE>
 __device__ __forceinline__ u64 list_key(const frame_dev& f, u32 sel) {
-    return sel == kNoKey32 ? kNoKey : make_key(sel_dist(sel), sel_entry(sel), f.g_entry[sel_entry(sel)].w);
+    const u32 entry = MODE == kModeTri ? 0xFFFFFu - sel_entry(sel) : sel_entry(sel);
+    return sel == kNoKey32 ? kNoKey : make_key(sel_dist(sel), sel_entry(sel), f.g_entry[entry].w);
 }
 
-template <int G, int K, bool FUSE>
+// robust::match_for_triangulation, robust.cc:106-121 and check_epipolar_constraint, robust.cc:317-335,
+// for the query of `c` and the keypoint `idx` of the searched keyframe (list entry j).
+//
+// The reference accepts when pi/2 - |acos(cos_residual)| < thr * scale_factor.  acos takes values in
+// [0, pi], so this is asin(cos_residual) < T and, asin being monotone, cos_residual < sin(T) (the
+// host passes sin(T) per query); NaN (a zero normal, or |cos_residual| > 1 by rounding) is never an
+// inlier.  The two forms can only disagree where rounding decides: the subtraction from pi/2 is exact
+// for cos_residual <= 0.7 and acos is good to an ulp of about 2.2e-16, so pairs whose cosine lies
+// within 1e-13 of sin(T) are borderline.  Those are reported to the host, which evaluates the
+// reference's expression with its own libm; a pair whose host result differs from the comparison
+// made here comes back in the override list and the match is redone.
+__device__ __forceinline__ bool tri_gate(const frame_dev& f, const query_ctx& c, u32 idx, u32 j, bool record) {
+    const double* b2 = f.bearings + 3 * (size_t)idx;
+    const double b2x = b2[0], b2y = b2[1], b2z = b2[2];
+    const double* E = f.tri_E;
+    const bool stereo2 = f.sxr && 0.0f <= f.sxr[idx];
+    if (!c.stereo1 && !stereo2) {
+        const double cos_dist = __dadd_rn(__dadd_rn(__dmul_rn(E[9], b2x), __dmul_rn(E[10], b2y)), __dmul_rn(E[11], b2z));
+        if (0.99862953475 < cos_dist) {
+            return false;
+        }
+    }
+    double e[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        e[r] = __dadd_rn(__dadd_rn(__dmul_rn(E[3 * r], b2x), __dmul_rn(E[3 * r + 1], b2y)), __dmul_rn(E[3 * r + 2], b2z));
+    }
+    const double dot = __dadd_rn(__dadd_rn(__dmul_rn(e[0], c.b1x), __dmul_rn(e[1], c.b1y)), __dmul_rn(e[2], c.b1z));
+    const double norm = __dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(e[0], e[0]), __dmul_rn(e[1], e[1])), __dmul_rn(e[2], e[2])));
+    const double cr = __ddiv_rn(dot, norm);
+    bool inlier = -1.0 <= cr && cr < c.sin_thr;
+    if (fabs(__dsub_rn(cr, c.sin_thr)) < 1e-13) {
+        if (record) {
+            const u32 slot = atomicAdd(&f.tri_amb[0], 1u);
+            if (slot < f.tri_amb[1]) {
+                f.tri_amb[2 + 2 * slot] = (u32)c.qi;
+                f.tri_amb[3 + 2 * slot] = j;
+            }
+        }
+        const u32 n_ovr = f.tri_ovr ? f.tri_ovr[0] : 0u;
+        for (u32 k = 0; k < n_ovr; ++k) {
+            if (f.tri_ovr[1 + 2 * k] == (u32)c.qi && f.tri_ovr[2 + 2 * k] == j) {
+                inlier = !inlier;
+                break;
+            }
+        }
+    }
+    return inlier;
+}
+
+template <int G, int K, int MODE>
 __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* qd, const uint8_t* occupied,
                             const u32* blocked, u32 (&top)[K], u32& total) {
     const int gl = threadIdx.x & (G - 1);
@@ -495,17 +602,28 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
             if (t < T) {
                 const u32 j = cs + (t - cexc);
                 const uint4 en = f.g_entry[j];
-                if (passes_gates<FUSE>(f, c, en, occupied, blocked, true)) {
+                if (passes_gates<MODE>(f, c, en, occupied, blocked, true)) {
                     const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
                     const u32 dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w)
                                      + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
-                    u32 key = (dist << 20) | j;
-                    ++cnt;
+                    bool keep = true;
+                    if (MODE == kModeTri) {
+                        // robust.cc:102 first, then the gates in double
+                        keep = dist <= kThrLow && tri_gate(f, c, en.w, j, blocked == nullptr);
+                    }
+                    else if (MODE == kModeArea) {
+                        // area.cc:46-49: a keypoint an earlier query holds at this distance or closer is skipped
+                        keep = !blocked || (blocked[en.w] >> 20) > dist;
+                    }
+                    if (keep) {
+                        u32 key = (dist << 20) | (MODE == kModeTri ? 0xFFFFFu - j : j);
+                        ++cnt;
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const u32 small = min(loc[k], key);
-                        key = max(loc[k], key);
-                        loc[k] = small;
+                        for (int k = 0; k < K; ++k) {
+                            const u32 small = min(loc[k], key);
+                            key = max(loc[k], key);
+                            loc[k] = small;
+                        }
                     }
                 }
             }
@@ -526,7 +644,7 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
     }
 }
 
-template <bool FUSE>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __restrict__ problems, proj_params pp) {
     const proj_problem& P = problems[blockIdx.y];
     constexpr int QPB = 256 / kGroup;
@@ -543,10 +661,10 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
     }
     query_ctx c;
     if (P.q.valid[qi]) {
-        if (make_query_ctx<FUSE>(pp, P.frm, P.q, qi, c)) {
+        if (make_query_ctx<MODE>(pp, P.frm, P.q, qi, c)) {
             u32 qd[8];
             load_desc(P.q.desc + 32 * (size_t)qi, qd);
-            window_topk<kGroup, kTopK, FUSE>(P.frm, c, qd, P.occupied, nullptr, top, total);
+            window_topk<kGroup, kTopK, MODE>(P.frm, c, qd, P.occupied, nullptr, top, total);
         }
         else if (gl == 0) {
             *P.err = OVS_ERR_OUT_OF_RANGE;
@@ -561,7 +679,7 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
             for (int k = 1; k < kTopK; ++k) {
                 v = slot == k ? top[k] : v;
             }
-            P.lists[(size_t)qi * kTopK + slot] = list_key(P.frm, v);
+            P.lists[(size_t)qi * kTopK + slot] = list_key<MODE>(P.frm, v);
         }
     }
     if (gl == 0) {
@@ -583,8 +701,9 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
             const u32 sd = second == kNoKey ? kMaxDist : key_dist(second);
             return !(bl == slv && (float)bd > __fmul_rn(pp.lowe, (float)sd));
         }
-        case kRange: {
-            // robust.cc:270-281, bow_tree.cc:80-87
+        case kRange:
+        case kArea: {
+            // robust.cc:270-281, bow_tree.cc:80-87, area.cc:61-68
             if (bd > kThrLow) {
                 return false;
             }
@@ -596,6 +715,7 @@ __device__ __forceinline__ bool accept_rule(const proj_params& pp, const frame_d
         case kSim3:
         case kFuseDetect:
         case kFuseReplace:
+        case kTri:
             return bd <= kThrLow;
         default:
             return bd <= kThrHigh; // kCurrLast, kOneWay
@@ -627,7 +747,7 @@ __device__ __forceinline__ void wave_sync() {
 
 // KIND >= 0 compiles the kernel for that one matcher (the kind tests fold away, which matters here:
 // the kernel is a single wavefront whose time is its instruction count); -1 = any kind.
-template <bool IN_LDS, bool FUSE, int KIND = -1>
+template <bool IN_LDS, int MODE, int KIND = -1>
 __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restrict__ problems, proj_params pp_arg, int lds_n) {
     proj_params pp = pp_arg;
     if (KIND >= 0) {
@@ -636,6 +756,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     extern __shared__ u32 sm[];
     __shared__ u32 hist[32];
     __shared__ u32 order[32];
+    __shared__ ovs_sort::sort_frame sort_stack[ovs_sort::kSortStackEntries];
     const proj_problem& P = problems[blockIdx.x];
     const int lane = threadIdx.x;
     const int n = P.frm.n, nq = P.q.n;
@@ -660,10 +781,17 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     }
     wave_sync();
 
+    constexpr bool AREA = MODE == kModeArea;
+    // kArea: `state` holds, per keypoint of the searched frame, distance << 20 | query of the match that
+    // currently owns it (all ones = free); it takes the place of the claim bitmap
+    u32* state = reinterpret_cast<u32*>(lmatched);
     const bool excl = !kind_is_one_way(pp.kind);
-    const int needed = (pp.kind == kFrameLms || pp.kind == kRange) ? 2 : 1;
+    const int needed = (pp.kind == kFrameLms || pp.kind == kRange || pp.kind == kArea) ? 2 : 1;
     const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr
-                                             : ((pp.kind == kSim3 || pp.kind == kRange || pp.kind == kFuseDetect || pp.kind == kFuseReplace) ? kThrLow : kThrHigh);
+                                             : ((pp.kind == kSim3 || pp.kind == kRange || pp.kind == kFuseDetect || pp.kind == kFuseReplace
+                                                 || pp.kind == kArea || pp.kind == kTri)
+                                                    ? kThrLow
+                                                    : kThrHigh);
     u32 mynum = 0;
     // the candidate list, count and flags of a chunk's query are fetched while the previous chunk is
     // being resolved
@@ -713,7 +841,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                     const u64 key = mykeys[k];
                     if (key != kNoKey && found < needed) { // the runner-up only matters to the ratio tests
                         const u32 idx = key_idx(key);
-                        const bool b = excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u);
+                        const bool b = AREA ? (state[idx] >> 20) <= key_dist(key) : (excl && ((blocked[idx >> 5] >> (idx & 31)) & 1u));
                         if (!b) {
                             if (found == 0) {
                                 best = key;
@@ -778,7 +906,15 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
                 const int first = undone ? __ffsll((long long)undone) - 1 : 64;
                 stop = min(first_rescan, first == 64 ? 64 : first + 1);
             }
-            if (accept && lane < stop) {
+            if (AREA) {
+                // area.cc:75-84: the keypoint changes hands; the previous owner's match is void from now
+                // on, which the final pass sees from the owner field
+                if (accept && lane < stop) {
+                    state[bidx] = (key_dist(best) << 20) | (u32)mq;
+                    myacc = (int)bidx;
+                }
+            }
+            else if (accept && lane < stop) {
                 if (excl) {
                     if (IN_LDS) {
                         lmatched[bidx] = mq;
@@ -803,17 +939,23 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
             if (stop == first_rescan) {
                 const int qi = base + stop;
                 query_ctx c;
-                make_query_ctx<FUSE>(pp, P.frm, P.q, qi, c);
+                make_query_ctx<MODE>(pp, P.frm, P.q, qi, c);
                 u32 qd[8];
                 load_desc(P.q.desc + 32 * (size_t)qi, qd);
                 u32 sel2[2];
                 u32 t2;
-                window_topk<64, 2, FUSE>(P.frm, c, qd, P.occupied, blocked, sel2, t2);
-                const u64 top2[2] = {list_key(P.frm, sel2[0]), list_key(P.frm, sel2[1])};
+                window_topk<64, 2, MODE>(P.frm, c, qd, P.occupied, AREA ? state : blocked, sel2, t2);
+                const u64 top2[2] = {list_key<MODE>(P.frm, sel2[0]), list_key<MODE>(P.frm, sel2[1])};
                 if (top2[0] != kNoKey && accept_rule(pp, P.frm, top2[0], top2[1])) {
                     const u32 ridx = key_idx(top2[0]);
                     const bool rblocks = __shfl((int)blocks, stop) != 0;
-                    if (lane == stop) {
+                    if (AREA) {
+                        if (lane == stop) {
+                            state[ridx] = (key_dist(top2[0]) << 20) | (u32)qi;
+                            myacc = (int)ridx;
+                        }
+                    }
+                    else if (lane == stop) {
                         if (IN_LDS) {
                             lmatched[ridx] = qi;
                         }
@@ -840,7 +982,53 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     wave_sync();
     u32 num = wave_sum_u32(mynum);
 
-    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm || pp.kind == kRange);
+    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm || pp.kind == kRange || pp.kind == kTri);
+    if (AREA) {
+        // area.cc:87-102.  The rotation histogram holds an entry for every match that was ever made,
+        // including those whose keypoint a later query took over (append_delta_angle is never undone);
+        // a match counts in the end if its query still owns the keypoint and, with the rotation check
+        // on, its bin is among the three fullest.  Every lane revisits the queries it wrote acc_idx for.
+        if (pp.check_orientation) {
+            for (int qi = lane; qi < nq; qi += 64) {
+                const int idx = P.acc_idx[qi];
+                if (0 <= idx) {
+                    int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                    if (bin < 0 || 30 <= bin) {
+                        *P.err = OVS_ERR_OUT_OF_RANGE;
+                        bin = 0;
+                    }
+                    atomicAdd(&hist[bin], 1u);
+                }
+            }
+            wave_sync();
+            if (lane == 0) {
+                ovs_sort::index_sort_by_size(hist, order, 30, sort_stack);
+            }
+            wave_sync();
+        }
+        const u32 v0 = order[0], v1 = order[1], v2 = order[2];
+        u32 kept = 0;
+        for (int qi = lane; qi < nq; qi += 64) {
+            const int idx = P.acc_idx[qi];
+            if (0 <= idx) {
+                bool ok = (state[idx] & 0xFFFFFu) == (u32)qi;
+                if (ok && pp.check_orientation) {
+                    int bin = angle_bin(__fsub_rn(P.q.angle[qi], P.frm.kps[idx].angle));
+                    bin = (bin < 0 || 30 <= bin) ? 0 : bin;
+                    ok = (u32)bin == v0 || (u32)bin == v1 || (u32)bin == v2;
+                }
+                if (!ok) {
+                    P.acc_idx[qi] = -1;
+                }
+                kept += ok ? 1u : 0u;
+            }
+        }
+        kept = wave_sum_u32(kept);
+        if (lane == 0) {
+            *P.num_matches = kept;
+        }
+        return;
+    }
     if (orient) {
         // rotation consistency, match/angle_checker.h: keep the three fullest of 30 bins.  Every lane
         // revisits exactly the queries it wrote acc_idx for.
@@ -881,7 +1069,7 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
         }
         wave_sync();
         if (lane == 0) {
-            ovs_sort::index_sort_by_size(hist, order, 30);
+            ovs_sort::index_sort_by_size(hist, order, 30, sort_stack);
         }
         wave_sync();
         const u32 v0 = order[0], v1 = order[1], v2 = order[2];
@@ -1033,7 +1221,14 @@ __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restr
         P.q.range_lo = nullptr;
         P.q.range_hi = nullptr;
         P.q.reproj_xy_d = nullptr;
+        P.q.bearings = nullptr;
+        P.q.sin_thr = nullptr;
+        P.q.stereo = nullptr;
         P.frm.inv_level_sigma_sq = nullptr;
+        P.frm.bearings = nullptr;
+        P.frm.tri_E = nullptr;
+        P.frm.tri_amb = nullptr;
+        P.frm.tri_ovr = nullptr;
         P.occupied = nullptr;
         P.lists = lists + qo * kTopK;
         P.totals = totals + qo;
@@ -1072,56 +1267,81 @@ size_t resolve_lds_bytes(int n, int lds_n) {
     return (static_cast<size_t>((n + 31) / 32) + 1) * 4;
 }
 
-// launches one instance of the resolve kernel; dynamic LDS beyond the default limit is requested
-// once per instance and size
+// launches one instance of the resolve kernel.  Dynamic LDS beyond the default limit is granted once
+// per (device, kernel instance), to the largest size the LDS plan above can ask for, and never lowered.
+constexpr size_t kResolveMaxLds = 150 * 1024 + 64;
+
 template <typename Kernel>
 int launch_resolve_instance(Kernel kernel, const proj_problem* d_prob, int n_problems, size_t bytes, int lds_n, const proj_params& pp, hipStream_t st) {
+    if (bytes > kResolveMaxLds) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "resolve kernel: LDS plan exceeds the limit");
+    }
     if (bytes > 48 * 1024) {
-        static thread_local size_t granted = 0; // per instance (the template argument is the function's type only: keyed below)
-        static thread_local const void* granted_for = nullptr;
+        static std::mutex mu;
+        static std::set<std::pair<int, const void*>> granted;
+        int dev = 0;
+        OVS_HIP(hipGetDevice(&dev));
         const void* fn = reinterpret_cast<const void*>(kernel);
-        if (granted_for != fn || granted < bytes) {
-            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
-            granted_for = fn;
-            granted = bytes;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!granted.count({dev, fn})) {
+            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kResolveMaxLds)));
+            granted.insert({dev, fn});
         }
     }
     OVS_LAUNCH("k_proj_resolve", kernel, dim3(n_problems), dim3(64), bytes, st, d_prob, pp, lds_n);
     return OVS_OK;
 }
 
-template <bool FUSE>
+template <int MODE>
 int launch_resolve_t(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
     const int lds_n = resolve_lds_n(max_n);
     const size_t bytes = resolve_lds_bytes(max_n, lds_n);
     if (lds_n > 0) {
         // the per-frame matchers of the tracking thread get a kernel compiled for their kind
-        if (!FUSE && pp.kind == kCurrLast) {
+        if (MODE == kModePlain && pp.kind == kCurrLast) {
             return launch_resolve_instance(k_proj_resolve<true, false, kCurrLast>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        if (!FUSE && pp.kind == kFrameLms) {
+        if (MODE == kModePlain && pp.kind == kFrameLms) {
             return launch_resolve_instance(k_proj_resolve<true, false, kFrameLms>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        if (!FUSE && pp.kind == kRange) {
+        if (MODE == kModePlain && pp.kind == kRange) {
             return launch_resolve_instance(k_proj_resolve<true, false, kRange>, d_prob, n_problems, bytes, lds_n, pp, st);
         }
-        return launch_resolve_instance(k_proj_resolve<true, FUSE>, d_prob, n_problems, bytes, lds_n, pp, st);
+        return launch_resolve_instance(k_proj_resolve<true, MODE>, d_prob, n_problems, bytes, lds_n, pp, st);
     }
-    return launch_resolve_instance(k_proj_resolve<false, FUSE>, d_prob, n_problems, bytes, 0, pp, st);
+    return launch_resolve_instance(k_proj_resolve<false, MODE>, d_prob, n_problems, bytes, 0, pp, st);
 }
 
 bool kind_is_fuse(int kind) { return kind == kFuseDetect || kind == kFuseReplace; }
 
 int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
-    return kind_is_fuse(pp.kind) ? launch_resolve_t<true>(d_prob, n_problems, max_n, pp, st) : launch_resolve_t<false>(d_prob, n_problems, max_n, pp, st);
+    if (kind_is_fuse(pp.kind)) {
+        return launch_resolve_t<kModeFuse>(d_prob, n_problems, max_n, pp, st);
+    }
+    if (pp.kind == kTri) {
+        return launch_resolve_t<kModeTri>(d_prob, n_problems, max_n, pp, st);
+    }
+    if (pp.kind == kArea) {
+        // the (distance, owner) state of every keypoint of the searched frame has to fit in LDS
+        const int lds_n = resolve_lds_n(max_n);
+        if (lds_n == 0) {
+            return ovs::fail(OVS_ERR_UNSUPPORTED, "match::area: too many keypoints in the searched frame");
+        }
+        return launch_resolve_instance(k_proj_resolve<true, kModeArea, kArea>, d_prob, n_problems, resolve_lds_bytes(max_n, lds_n), lds_n, pp, st);
+    }
+    return launch_resolve_t<kModePlain>(d_prob, n_problems, max_n, pp, st);
 }
 
 void launch_candidates(dim3 grid, const proj_problem* d_prob, const proj_params& pp, hipStream_t st) {
     if (kind_is_fuse(pp.kind)) {
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<true>, grid, dim3(256), 0, st, d_prob, pp);
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeFuse>, grid, dim3(256), 0, st, d_prob, pp);
+    }
+    else if (pp.kind == kTri) {
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeTri>, grid, dim3(256), 0, st, d_prob, pp);
     }
     else {
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<false>, grid, dim3(256), 0, st, d_prob, pp);
+        // kArea included: the take-over rule only acts in the resolve kernel
+        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModePlain>, grid, dim3(256), 0, st, d_prob, pp);
     }
 }
 
@@ -1333,6 +1553,17 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
 
 // A matching problem whose queries each scan one contiguous range of a candidate list
 // (robust::brute_force_match: the whole list; bow_tree::match_*: the bucket of the query's node).
+// The extra inputs of robust::match_for_triangulation on top of a ranged problem.
+struct tri_extra {
+    const double* cand_bearings = nullptr; // n_cand x 3
+    const float* cand_sxr = nullptr;       // n_cand or nullptr (monocular)
+    const double* q_bearings = nullptr;    // nq x 3, query order
+    const double* q_sin_thr = nullptr;     // nq
+    const double* q_thr = nullptr;         // nq: residual threshold in radians (host re-check)
+    const uint8_t* q_stereo = nullptr;     // nq
+    double E[12];                          // E_12 row-major, then the epipole
+};
+
 struct ranged_problem {
     const uint8_t* cand_descs = nullptr; // n_cand x 32
     const float* cand_angles = nullptr;  // n_cand or nullptr
@@ -1347,7 +1578,20 @@ struct ranged_problem {
     int nq = 0;
     float lowe = 0;
     int check_orientation = 0, angle_sign = 1, per_query_output = 0;
+    const tri_extra* tri = nullptr; // non-null: kTri instead of kRange
 };
+
+// cos_residual of check_epipolar_constraint (robust.cc:320-323) in the operation order of tri_gate
+// (IEEE double operations, no contraction: the host and the device get the same bits)
+double tri_cos_residual(const double* E, const double* b1, const double* b2) {
+    double e[3];
+    for (int r = 0; r < 3; ++r) {
+        e[r] = (E[3 * r] * b2[0] + E[3 * r + 1] * b2[1]) + E[3 * r + 2] * b2[2];
+    }
+    const double dot = (e[0] * b1[0] + e[1] * b1[1]) + e[2] * b1[2];
+    const double norm = std::sqrt((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]);
+    return dot / norm;
+}
 
 int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out, uint32_t* num_matches, int device) {
     int rc = check_device(device);
@@ -1363,114 +1607,197 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
         return rc;
     }
     const size_t n = rp.n_cand, ne = rp.n_entries, nq = rp.nq;
-    const size_t total = al(n * sizeof(ovs_keypoint)) + al(n * 32) + al(n) + al(ne * 4) + al(ne * 16) + al(ne * 32) + al(nq * 32) + al(nq * 4) * 5
-                         + al(nq) + al(nq * kTopK * 8) + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem));
-    if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
-        return rc;
-    }
-    carver cv;
-    cv.base = ctx->arena.as<uint8_t>();
-    hipStream_t st = ctx->stream;
-    host_stager hs;
-    if ((rc = hs.init(ctx, st)) != OVS_OK) {
-        return rc;
-    }
+    const tri_extra* tri = rp.tri;
     // candidate keypoints only carry the angle (read by the rotation check)
     std::vector<ovs_keypoint> kps(n);
     for (size_t i = 0; i < n; ++i) {
         kps[i] = ovs_keypoint{0.f, 0.f, 0.f, rp.cand_angles ? rp.cand_angles[i] : 0.f, 0.f, 0, -1};
     }
+    // kTri: borderline epipolar decisions go through the host (tri_gate); `ovr` lists the pairs whose
+    // exact result is the opposite of the device's comparison.  The set of borderline pairs depends on
+    // the inputs alone, so one repetition with the overrides in place settles the match.
+    size_t amb_cap = 1024;
+    std::vector<u32> ovr, amb;
+    for (int attempt = 0;; ++attempt) {
+        const size_t n_ovr = ovr.size() / 2;
+        const size_t total = al(n * sizeof(ovs_keypoint)) + al(n * 32) + al(n) + al(ne * 4) + al(ne * 16) + al(ne * 32) + al(nq * 32) + al(nq * 4) * 5
+                             + al(nq) + al(nq * kTopK * 8) + al(n * 4) + al(256) * 3 + al(sizeof(proj_problem))
+                             + (tri ? al(n * 24) + al(n * 4) + al(nq * 24) + al(nq * 8) + al(nq) + al(12 * 8) + al((2 + 2 * amb_cap) * 4) + al((1 + 2 * n_ovr) * 4) : 0);
+        if ((rc = ctx->arena.reserve(total)) != OVS_OK) {
+            return rc;
+        }
+        carver cv;
+        cv.base = ctx->arena.as<uint8_t>();
+        hipStream_t st = ctx->stream;
+        host_stager hs;
+        if ((rc = hs.init(ctx, st)) != OVS_OK) {
+            return rc;
+        }
 
-    auto* d_kps = cv.take<ovs_keypoint>(n);
-    auto* d_desc = cv.take<uint8_t>(n * 32);
-    auto* d_occ = cv.take<uint8_t>(n);
-    auto* d_eidx = cv.take<u32>(ne);
-    auto* d_qdesc = cv.take<uint8_t>(nq * 32);
-    auto* d_ang = cv.take<float>(nq);
-    auto* d_lo = cv.take<u32>(nq);
-    auto* d_hi = cv.take<u32>(nq);
-    auto* d_valid = cv.take<uint8_t>(nq);
-    auto* d_prob = cv.take<proj_problem>(1);
-    // results (one span for the way back) and kernel-to-kernel buffers
-    auto* d_acc = cv.take<int>(nq);
-    auto* d_matched = cv.take<int>(n);
-    auto* d_num = cv.take<u32>(1);
-    auto* d_err = cv.take<int>(1);
-    auto* d_totals = cv.take<u32>(nq);
-    auto* d_lists = cv.take<u64>(nq * kTopK);
-    auto* d_entry = cv.take<uint4>(ne);
-    auto* d_gdesc = cv.take<uint4>(2 * ne);
+        auto* d_kps = cv.take<ovs_keypoint>(n);
+        auto* d_desc = cv.take<uint8_t>(n * 32);
+        auto* d_occ = cv.take<uint8_t>(n);
+        auto* d_eidx = cv.take<u32>(ne);
+        auto* d_qdesc = cv.take<uint8_t>(nq * 32);
+        auto* d_ang = cv.take<float>(nq);
+        auto* d_lo = cv.take<u32>(nq);
+        auto* d_hi = cv.take<u32>(nq);
+        auto* d_valid = cv.take<uint8_t>(nq);
+        double *d_cb = nullptr, *d_qb = nullptr, *d_qs = nullptr, *d_E = nullptr;
+        float* d_csxr = nullptr;
+        uint8_t* d_qst = nullptr;
+        u32* d_ovr = nullptr;
+        if (tri) {
+            d_cb = cv.take<double>(n * 3);
+            d_csxr = cv.take<float>(n);
+            d_qb = cv.take<double>(nq * 3);
+            d_qs = cv.take<double>(nq);
+            d_qst = cv.take<uint8_t>(nq);
+            d_E = cv.take<double>(12);
+            d_ovr = cv.take<u32>(1 + 2 * n_ovr);
+        }
+        auto* d_prob = cv.take<proj_problem>(1);
+        // results (one span for the way back) and kernel-to-kernel buffers
+        auto* d_acc = cv.take<int>(nq);
+        auto* d_matched = cv.take<int>(n);
+        auto* d_num = cv.take<u32>(1);
+        auto* d_err = cv.take<int>(1);
+        u32* d_amb = tri ? cv.take<u32>(2 + 2 * amb_cap) : nullptr;
+        auto* d_totals = cv.take<u32>(nq);
+        auto* d_lists = cv.take<u64>(nq * kTopK);
+        auto* d_entry = cv.take<uint4>(ne);
+        auto* d_gdesc = cv.take<uint4>(2 * ne);
 
-    hs.put(d_kps, kps.data(), n * sizeof(ovs_keypoint));
-    hs.put(d_desc, rp.cand_descs, n * 32);
-    if (rp.cand_occupied) {
-        hs.put(d_occ, rp.cand_occupied, n);
-    }
-    hs.put(d_eidx, rp.entry_idx, ne * 4);
-    hs.put(d_qdesc, rp.q_descs, nq * 32);
-    if (rp.q_angles) {
-        hs.put(d_ang, rp.q_angles, nq * 4);
-    }
-    hs.put(d_lo, rp.q_lo, nq * 4);
-    hs.put(d_hi, rp.q_hi, nq * 4);
-    hs.fill(d_valid, 1, nq);
-    hs.fill(d_acc, 0xFF, nq * 4);
-    hs.fill(d_num, 0, 4);
-    hs.fill(d_err, 0, 4);
+        hs.put(d_kps, kps.data(), n * sizeof(ovs_keypoint));
+        hs.put(d_desc, rp.cand_descs, n * 32);
+        if (rp.cand_occupied) {
+            hs.put(d_occ, rp.cand_occupied, n);
+        }
+        hs.put(d_eidx, rp.entry_idx, ne * 4);
+        hs.put(d_qdesc, rp.q_descs, nq * 32);
+        if (rp.q_angles) {
+            hs.put(d_ang, rp.q_angles, nq * 4);
+        }
+        hs.put(d_lo, rp.q_lo, nq * 4);
+        hs.put(d_hi, rp.q_hi, nq * 4);
+        hs.fill(d_valid, 1, nq);
+        hs.fill(d_acc, 0xFF, nq * 4);
+        hs.fill(d_num, 0, 4);
+        hs.fill(d_err, 0, 4);
 
-    proj_problem P;
-    std::memset(&P, 0, sizeof(P));
-    P.frm.n = static_cast<int>(n);
-    P.frm.kps = d_kps;
-    P.frm.desc = d_desc;
-    P.frm.num_levels = 1;
-    P.frm.grid.num_cols = P.frm.grid.num_rows = 1;
-    P.frm.g_entry = d_entry;
-    P.frm.g_desc = d_gdesc;
-    P.q.n = static_cast<int>(nq);
-    P.q.angle = d_ang;
-    P.q.desc = d_qdesc;
-    P.q.valid = d_valid;
-    P.q.range_lo = d_lo;
-    P.q.range_hi = d_hi;
-    P.occupied = rp.cand_occupied ? d_occ : nullptr;
-    P.lists = d_lists;
-    P.totals = d_totals;
-    P.matched = d_matched;
-    P.num_matches = d_num;
-    P.acc_idx = d_acc;
-    P.err = d_err;
-    hs.put(d_prob, &P, sizeof(P));
-    OVS_HIP(hs.upload());
+        proj_problem P;
+        std::memset(&P, 0, sizeof(P));
+        if (tri) {
+            hs.put(d_cb, tri->cand_bearings, n * 24);
+            if (tri->cand_sxr) {
+                hs.put(d_csxr, tri->cand_sxr, n * 4);
+            }
+            hs.put(d_qb, tri->q_bearings, nq * 24);
+            hs.put(d_qs, tri->q_sin_thr, nq * 8);
+            hs.put(d_qst, tri->q_stereo, nq);
+            hs.put(d_E, tri->E, 12 * 8);
+            const u32 amb_head[2] = {0u, static_cast<u32>(amb_cap)};
+            hs.put(d_amb, amb_head, 8);
+            const u32 ovr_head = static_cast<u32>(n_ovr);
+            hs.put(d_ovr, &ovr_head, 4);
+            hs.put(d_ovr + 1, ovr.data(), n_ovr * 8);
+            P.frm.bearings = d_cb;
+            P.frm.sxr = tri->cand_sxr ? d_csxr : nullptr;
+            P.frm.tri_E = d_E;
+            P.frm.tri_amb = d_amb;
+            P.frm.tri_ovr = d_ovr;
+            P.q.bearings = d_qb;
+            P.q.sin_thr = d_qs;
+            P.q.stereo = d_qst;
+        }
+        P.frm.n = static_cast<int>(n);
+        P.frm.kps = d_kps;
+        P.frm.desc = d_desc;
+        P.frm.num_levels = 1;
+        P.frm.grid.num_cols = P.frm.grid.num_rows = 1;
+        P.frm.g_entry = d_entry;
+        P.frm.g_desc = d_gdesc;
+        P.q.n = static_cast<int>(nq);
+        P.q.angle = d_ang;
+        P.q.desc = d_qdesc;
+        P.q.valid = d_valid;
+        P.q.range_lo = d_lo;
+        P.q.range_hi = d_hi;
+        P.occupied = rp.cand_occupied ? d_occ : nullptr;
+        P.lists = d_lists;
+        P.totals = d_totals;
+        P.matched = d_matched;
+        P.num_matches = d_num;
+        P.acc_idx = d_acc;
+        P.err = d_err;
+        hs.put(d_prob, &P, sizeof(P));
+        OVS_HIP(hs.upload());
 
-    proj_params pp{kRange, 0.0f, OVS_DIR_NONE, 0, rp.lowe, kThrLow, rp.check_orientation, rp.angle_sign, rp.per_query_output};
-    if (ne) {
-        OVS_LAUNCH("k_entries_from_list", k_entries_from_list, dim3((ne + 255) / 256), dim3(256), 0, st, d_eidx, static_cast<int>(ne), d_desc, d_entry, d_gdesc);
+        proj_params pp{tri ? kTri : kRange, 0.0f, OVS_DIR_NONE, 0, rp.lowe, kThrLow, rp.check_orientation, rp.angle_sign, rp.per_query_output};
+        if (ne) {
+            OVS_LAUNCH("k_entries_from_list", k_entries_from_list, dim3((ne + 255) / 256), dim3(256), 0, st, d_eidx, static_cast<int>(ne), d_desc, d_entry, d_gdesc);
+        }
+        if (nq) {
+            constexpr int QPB = 256 / kGroup;
+            launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
+        }
+        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
+            return rc;
+        }
+        OVS_HIP(hipGetLastError());
+        int err = 0;
+        uint32_t num = 0;
+        if (matched_out) {
+            hs.get(matched_out, d_matched, n * 4);
+        }
+        if (acc_out) {
+            hs.get(acc_out, d_acc, nq * 4);
+        }
+        hs.get(&num, d_num, 4);
+        hs.get(&err, d_err, 4);
+        if (tri) {
+            amb.assign(2 + 2 * amb_cap, 0u);
+            hs.get(amb.data(), d_amb, amb.size() * 4);
+        }
+        OVS_HIP(hs.download());
+        if (err != 0) {
+            return ovs::fail(err, "rotation bin out of range");
+        }
+        *num_matches = num;
+        if (!tri || amb[0] == 0) {
+            return OVS_OK;
+        }
+        if (amb[0] > amb_cap) {
+            amb_cap = amb[0]; // room for every borderline pair, then once more
+            continue;
+        }
+        std::vector<std::pair<u32, u32>> flips;
+        for (u32 k = 0; k < amb[0]; ++k) {
+            const u32 qi = amb[2 + 2 * k], j = amb[3 + 2 * k];
+            const u32 idx_2 = rp.entry_idx[j];
+            const double cr = tri_cos_residual(tri->E, tri->q_bearings + 3 * static_cast<size_t>(qi), tri->cand_bearings + 3 * static_cast<size_t>(idx_2));
+            const bool dev = -1.0 <= cr && cr < tri->q_sin_thr[qi];
+            // the reference's expression (robust.cc:324-334) with the host's libm
+            const double residual_rad = M_PI / 2.0 - std::abs(std::acos(cr));
+            const bool exact = residual_rad < tri->q_thr[qi];
+            if (dev != exact) {
+                flips.emplace_back(qi, j);
+            }
+        }
+        std::sort(flips.begin(), flips.end());
+        std::vector<u32> want;
+        for (const auto& f : flips) {
+            want.push_back(f.first);
+            want.push_back(f.second);
+        }
+        if (want == ovr) {
+            return OVS_OK; // this run already used the exact decisions
+        }
+        if (attempt >= 3) {
+            return ovs::fail(OVS_ERR_HIP, "triangulation matcher: borderline epipolar decisions did not settle");
+        }
+        ovr.swap(want);
     }
-    if (nq) {
-        constexpr int QPB = 256 / kGroup;
-        launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
-    }
-    if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
-        return rc;
-    }
-    OVS_HIP(hipGetLastError());
-    int err = 0;
-    uint32_t num = 0;
-    if (matched_out) {
-        hs.get(matched_out, d_matched, n * 4);
-    }
-    if (acc_out) {
-        hs.get(acc_out, d_acc, nq * 4);
-    }
-    hs.get(&num, d_num, 4);
-    hs.get(&err, d_err, 4);
-    OVS_HIP(hs.download());
-    if (err != 0) {
-        return ovs::fail(err, "rotation bin out of range");
-    }
-    *num_matches = num;
-    return OVS_OK;
 }
 
 // Queries of the BoW matchers in the reference's iteration order: the merge-join over the two
@@ -1837,6 +2164,171 @@ int ovs_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
             matched_idx2_in_kf1[bq.q_src[q]] = acc[q];
         }
     }
+    return OVS_OK;
+}
+
+int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
+                                const ovs_keypoint* undist_keypts_1, const double* bearings_1,
+                                const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,
+                                const ovs_bow_feat_vec* vec_2, const uint8_t* descs_2,
+                                const ovs_keypoint* undist_keypts_2, const double* bearings_2,
+                                const float* stereo_x_right_2, const uint8_t* has_lm_2, int n2,
+                                const double* E_12, const double* epipole_in_2,
+                                const float* scale_factors_1, int num_scale_levels_1,
+                                int check_orientation,
+                                uint32_t* pairs, uint32_t* num_matches, int device) {
+    // robust::match_for_triangulation (robust.cc:18-172).  Queries = the keypoints of keyframe 1
+    // without a landmark, in the order of the merge-join over the two feature vectors; the candidates
+    // of a query are the keypoints of keyframe 2 in the same vocabulary node.  Distances, both
+    // epipolar gates and the sequential "already matched" rule run on the device.
+    int rc;
+    if ((rc = validate_bow(vec_1)) != OVS_OK || (rc = validate_bow(vec_2)) != OVS_OK) {
+        return rc;
+    }
+    if (n1 < 0 || n2 < 0 || !E_12 || !epipole_in_2 || !scale_factors_1 || !pairs || !num_matches
+        || (n1 > 0 && (!descs_1 || !undist_keypts_1 || !bearings_1)) || (n2 > 0 && (!descs_2 || !undist_keypts_2 || !bearings_2))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    std::vector<u32> q_src, lo, hi;
+    std::vector<uint8_t> qd, q_stereo;
+    std::vector<float> qa;
+    std::vector<double> qb, q_thr, q_sin;
+    {
+        int a = 0, b = 0;
+        while (a != vec_1->num_nodes && b != vec_2->num_nodes) {
+            if (vec_1->node_ids[a] == vec_2->node_ids[b]) {
+                for (u32 k = vec_1->offsets[a]; k < vec_1->offsets[a + 1]; ++k) {
+                    const u32 idx_1 = vec_1->indices[k];
+                    if (static_cast<int>(idx_1) >= n1) {
+                        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
+                    }
+                    if (has_lm_1 && has_lm_1[idx_1]) {
+                        continue; // robust.cc:62-66
+                    }
+                    const ovs_keypoint& keypt_1 = undist_keypts_1[idx_1];
+                    if (keypt_1.octave < 0 || num_scale_levels_1 <= keypt_1.octave) {
+                        return ovs::fail(OVS_ERR_OUT_OF_RANGE, "octave out of range"); // scale_factors_.at(), robust.cc:120
+                    }
+                    q_src.push_back(idx_1);
+                    lo.push_back(vec_2->offsets[b]);
+                    hi.push_back(vec_2->offsets[b + 1]);
+                    qd.insert(qd.end(), descs_1 + 32 * static_cast<size_t>(idx_1), descs_1 + 32 * static_cast<size_t>(idx_1) + 32);
+                    qa.push_back(keypt_1.angle);
+                    qb.insert(qb.end(), bearings_1 + 3 * static_cast<size_t>(idx_1), bearings_1 + 3 * static_cast<size_t>(idx_1) + 3);
+                    q_stereo.push_back(0 <= (stereo_x_right_1 ? stereo_x_right_1[idx_1] : -1.0f) ? 1 : 0);
+                    // residual_rad_thr * bearing_1_scale_factor, robust.cc:329-334 (the float factor widens)
+                    constexpr double residual_rad_thr = 0.2 * M_PI / 180.0;
+                    const double thr = residual_rad_thr * scale_factors_1[keypt_1.octave];
+                    q_thr.push_back(thr);
+                    q_sin.push_back(std::sin(thr));
+                }
+                ++a;
+                ++b;
+            }
+            else if (vec_1->node_ids[a] < vec_2->node_ids[b]) {
+                a = static_cast<int>(std::lower_bound(vec_1->node_ids, vec_1->node_ids + vec_1->num_nodes, vec_2->node_ids[b]) - vec_1->node_ids);
+            }
+            else {
+                b = static_cast<int>(std::lower_bound(vec_2->node_ids, vec_2->node_ids + vec_2->num_nodes, vec_1->node_ids[a]) - vec_2->node_ids);
+            }
+        }
+    }
+    const u32 n_entries = vec_2->num_nodes ? vec_2->offsets[vec_2->num_nodes] : 0;
+    for (u32 k = 0; k < n_entries; ++k) {
+        if (static_cast<int>(vec_2->indices[k]) >= n2) {
+            return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
+        }
+    }
+    std::vector<float> angles_2(n2);
+    for (int i = 0; i < n2; ++i) {
+        angles_2[i] = undist_keypts_2[i].angle;
+    }
+    tri_extra tx;
+    tx.cand_bearings = bearings_2;
+    tx.cand_sxr = stereo_x_right_2;
+    tx.q_bearings = qb.data();
+    tx.q_sin_thr = q_sin.data();
+    tx.q_thr = q_thr.data();
+    tx.q_stereo = q_stereo.data();
+    std::memcpy(tx.E, E_12, 9 * sizeof(double));
+    std::memcpy(tx.E + 9, epipole_in_2, 3 * sizeof(double));
+    ranged_problem rp;
+    rp.cand_descs = descs_2;
+    rp.cand_angles = angles_2.data();
+    rp.n_cand = n2;
+    rp.cand_occupied = has_lm_2; // robust.cc:81-85
+    rp.entry_idx = vec_2->indices;
+    rp.n_entries = static_cast<int>(n_entries);
+    rp.q_descs = qd.data();
+    rp.q_angles = qa.data();
+    rp.q_lo = lo.data();
+    rp.q_hi = hi.data();
+    rp.nq = static_cast<int>(q_src.size());
+    rp.check_orientation = check_orientation;
+    rp.angle_sign = 1;       // keypt_1.angle - keyframe-2 angle, robust.cc:136-137
+    rp.per_query_output = 1; // the rotation check clears matched_indices_2_in_keyfrm_1[idx_1]
+    rp.tri = &tx;
+    std::vector<int32_t> acc(q_src.size(), -1);
+    if ((rc = run_ranged(rp, nullptr, acc.data(), num_matches, device)) != OVS_OK) {
+        return rc;
+    }
+    std::vector<int32_t> matched_indices_2_in_keyfrm_1(n1, -1);
+    for (size_t q = 0; q < q_src.size(); ++q) {
+        if (0 <= acc[q]) {
+            matched_indices_2_in_keyfrm_1[q_src[q]] = acc[q];
+        }
+    }
+    unsigned k = 0;
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 <= matched_indices_2_in_keyfrm_1[idx_1]) {
+            pairs[2 * k] = static_cast<uint32_t>(idx_1);
+            pairs[2 * k + 1] = static_cast<uint32_t>(matched_indices_2_in_keyfrm_1[idx_1]);
+            ++k;
+        }
+    }
+    return OVS_OK;
+}
+
+int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
+                                 const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
+                                 float lowe_ratio, int check_orientation,
+                                 int32_t* matched_indices_2_in_frm_1, uint32_t* num_matches, int device) {
+    // area::match_in_consistent_area (area.cc:8-112): every keypoint of frame 1 is a query (only those
+    // at scale level 0 search, area.cc:24-26) around its previously matched point; the window scan,
+    // the distances and the sequential take-over rule run on the device.
+    if (n1 < 0 || !frm_2 || !num_matches || (n1 > 0 && (!undist_keypts_1 || !descs_1 || !prev_matched_pts || !matched_indices_2_in_frm_1))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    std::vector<int32_t> sl(n1);
+    std::vector<float> ang(n1);
+    std::vector<uint8_t> valid(n1);
+    for (int i = 0; i < n1; ++i) {
+        sl[i] = undist_keypts_1[i].octave;
+        ang[i] = undist_keypts_1[i].angle;
+        valid[i] = 0 < undist_keypts_1[i].octave ? 0 : 1;
+    }
+    ovs_proj_queries q;
+    std::memset(&q, 0, sizeof(q));
+    q.n = n1;
+    q.reproj_xy = prev_matched_pts;
+    q.scale_level = sl.data();
+    q.angle = ang.data();
+    q.desc = descs_1;
+    q.valid = valid.data();
+    uint32_t num = 0;
+    proj_params pp{kArea, static_cast<float>(margin), OVS_DIR_NONE, 0, lowe_ratio, kThrLow, check_orientation, 1, 1};
+    int rc = run_projection(frm_2, &q, nullptr, pp, nullptr, matched_indices_2_in_frm_1, &num, device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    for (int idx_1 = 0; idx_1 < n1; ++idx_1) {
+        if (0 <= matched_indices_2_in_frm_1[idx_1]) { // area.cc:105-109
+            const ovs_keypoint& kp = frm_2->undist_keypts[matched_indices_2_in_frm_1[idx_1]];
+            prev_matched_pts[2 * idx_1] = kp.x;
+            prev_matched_pts[2 * idx_1 + 1] = kp.y;
+        }
+    }
+    *num_matches = num;
     return OVS_OK;
 }
 

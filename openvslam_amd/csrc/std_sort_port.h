@@ -175,8 +175,18 @@ OVS_HD inline void insertion_sort(unsigned* first, unsigned* last, Comp comp) {
     }
 }
 
+// One pending range of the introsort loop, as offsets from the start of the array.
+struct sort_frame {
+    int first, last, depth;
+};
+// The explicit stack holds at most one entry per level of the depth limit 2 * floor(log2(n)) plus
+// one: 13 entries for n <= 64.
+constexpr int kSortStackEntries = 16;
+
+// `stack`: kSortStackEntries entries of working memory (a kernel passes LDS: a local array that is
+// indexed dynamically would live in scratch memory).
 template <typename Comp>
-OVS_HD inline void std_sort(unsigned* first, unsigned* last, Comp comp) {
+OVS_HD inline void std_sort(unsigned* first, unsigned* last, Comp comp, sort_frame* stack) {
     const long threshold = 16;
     if (first == last) {
         return;
@@ -187,27 +197,25 @@ OVS_HD inline void std_sort(unsigned* first, unsigned* last, Comp comp) {
     while ((n >> (lg + 1)) != 0) {
         ++lg;
     }
-    struct frame {
-        unsigned *first, *last;
-        int depth;
-    };
-    frame stack[64];
     int sp = 0;
-    stack[sp++] = frame{first, last, 2 * lg};
+    stack[sp++] = sort_frame{0, (int)n, 2 * lg};
     while (sp > 0) {
-        frame f = stack[--sp];
-        while (f.last - f.first > threshold) {
-            if (f.depth == 0) {
-                heap_sort_all(f.first, f.last, comp);
-                f.last = f.first;
+        const sort_frame f = stack[--sp];
+        unsigned* f_first = first + f.first;
+        unsigned* f_last = first + f.last;
+        int depth = f.depth;
+        while (f_last - f_first > threshold) {
+            if (depth == 0) {
+                heap_sort_all(f_first, f_last, comp);
+                f_last = f_first;
                 break;
             }
-            --f.depth;
-            unsigned* cut = unguarded_partition_pivot(f.first, f.last, comp);
+            --depth;
+            unsigned* cut = unguarded_partition_pivot(f_first, f_last, comp);
             // the recursive call sorts [cut, last) first, then the loop continues on [first, cut);
             // partitions of disjoint ranges commute, so the order of processing does not matter
-            stack[sp++] = frame{cut, f.last, f.depth};
-            f.last = cut;
+            stack[sp++] = sort_frame{(int)(cut - first), (int)(f_last - first), depth};
+            f_last = cut;
         }
     }
     // __final_insertion_sort
@@ -223,12 +231,17 @@ OVS_HD inline void std_sort(unsigned* first, unsigned* last, Comp comp) {
 }
 
 // index_sort_by_size of angle_checker.h:126-134: idx = 0..n-1 sorted by size descending
-OVS_HD inline void index_sort_by_size(const unsigned* size, unsigned* idx, int n) {
+OVS_HD inline void index_sort_by_size(const unsigned* size, unsigned* idx, int n, sort_frame* stack) {
     for (int i = 0; i < n; ++i) {
         idx[i] = (unsigned)i;
     }
     by_size_desc comp{size};
-    std_sort(idx, idx + n, comp);
+    std_sort(idx, idx + n, comp, stack);
+}
+// host convenience: the stack is a local array
+inline void index_sort_by_size(const unsigned* size, unsigned* idx, int n) {
+    sort_frame stack[kSortStackEntries];
+    index_sort_by_size(size, idx, n, stack);
 }
 
 } // namespace ovs_sort

@@ -73,3 +73,54 @@ def test_gpu_matches_oracle_on_a_sequence(check, lowe, margin):
     assert got_num == want_num and np.array_equal(got_m, want_m)
     assert got_prev.tobytes() == want_prev.tobytes()
     assert got_num > 50
+
+
+@pytest.mark.gpu
+def test_gpu_closer_keypoint_takes_over():
+    """The three-query case of test_closer_keypoint_takes_over through the device path."""
+    from openvslam_amd import match
+    k1 = np.zeros(3, dtype=A.KEYPOINT_DTYPE)
+    k1["x"], k1["y"] = 100.0, 100.0
+    k2 = np.zeros(1, dtype=A.KEYPOINT_DTYPE)
+    k2["x"], k2["y"] = 101.0, 100.0
+    d2 = np.zeros((1, 32), np.uint8)
+    d1 = np.zeros((3, 32), np.uint8)
+    d1[0, 0], d1[1, 0], d1[2, 0] = 0x0F, 0x03, 0x30
+    view = A.make_frame_view(k2, d2, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.full((3, 2), 100.0, np.float32)
+    num, m = match.area(0.9, False).match_in_consistent_area(k1, d1, view, prev, 10)
+    assert num == 1 and m.tolist() == [-1, 1 - 1, -1]
+    assert prev.tolist() == [[100.0, 100.0], [101.0, 100.0], [100.0, 100.0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n1,n2,check,lowe,margin", [(1, 3000, 200, 1, 0.9, 60), (2, 1500, 40, 0, 1.0, 200), (3, 2500, 900, 1, 0.8, 25)])
+def test_gpu_contested_keypoints(seed, n1, n2, check, lowe, margin):
+    """Many keypoints of frame 1 compete for few keypoints of frame 2 (area.cc:46-49,75-85): matches
+    change hands repeatedly, windows hold far more candidates than a query's candidate list, and the
+    rotation histogram keeps the entries of matches that were taken over later (area.cc:87-91)."""
+    from openvslam_amd import match
+    rng = np.random.default_rng(seed)
+    k2 = np.zeros(n2, dtype=A.KEYPOINT_DTYPE)
+    k2["x"], k2["y"] = rng.uniform(200, 330, n2), rng.uniform(150, 260, n2)
+    k2["angle"] = rng.uniform(0, 360, n2)
+    k2["octave"] = rng.integers(0, 2, n2)
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.integers(0, n2, n1)
+    d1 = d2[src].copy()
+    for i in range(n1):
+        for b in rng.choice(256, rng.integers(0, 45), replace=False):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    k1 = np.zeros(n1, dtype=A.KEYPOINT_DTYPE)
+    k1["x"] = k2["x"][src] + rng.normal(0, 8, n1).astype(np.float32)
+    k1["y"] = k2["y"][src] + rng.normal(0, 8, n1).astype(np.float32)
+    k1["angle"] = (k2["angle"][src] + rng.normal(0, 25, n1)) % 360
+    k1["octave"] = (rng.random(n1) < 0.1).astype(np.int32)
+    view2 = A.make_frame_view(k2, d2, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32))
+    want_num, want_m, want_prev = oracle_area(k1, d1, view2, prev, margin, lowe, check)
+    got_prev = prev.copy()
+    got_num, got_m = match.area(lowe, bool(check)).match_in_consistent_area(k1, d1, view2, got_prev, margin)
+    assert got_num == want_num and np.array_equal(got_m, want_m)
+    assert got_prev.tobytes() == want_prev.tobytes()
+    assert 0 < got_num <= n2

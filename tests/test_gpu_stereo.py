@@ -311,3 +311,92 @@ def test_match_for_triangulation(seed, n, words, check):
     assert res[0][1] == res[1][1]
     assert np.array_equal(res[0][0], res[1][0])
     assert res[0][1] > n // 20
+
+
+def test_match_for_triangulation_borderline_epipolar_decisions():
+    """Pairs whose epipolar residual sits within a few hundred ulps of the threshold: the reference
+    decides them through acos of its libm (robust.cc:324-334), the device compares cosines and hands
+    such pairs to the host.  With E = identity, bearing_2 = (0, 0, 1) and bearing_1 = (., 0, c) the
+    cosine of the residual is exactly c, so c = sin(threshold) + k ulp plants the case."""
+    import math
+    thr = 0.2 * math.pi / 180.0
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    ks = list(range(-330, 331, 3))
+    levels = [0, 1, 5, 7]
+    n = len(ks) * len(levels)
+    b1 = np.zeros((n, 3))
+    b2 = np.zeros((n, 3))
+    k1 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k2 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    flips = 0
+    i = 0
+    for lv in levels:
+        T = thr * float(sf[lv])
+        s = math.sin(T)
+        for k in ks:
+            c = float(np.float64(s) + k * np.spacing(np.float64(s)))
+            b1[i] = (math.sqrt(1.0 - c * c), 0.0, c)
+            b2[i] = (0.0, 0.0, 1.0)
+            k1["octave"][i] = lv
+            flips += int((c < s) != ((math.pi / 2.0 - abs(math.acos(c))) < T))
+            i += 1
+    assert flips > 10, "the planted cosines no longer straddle the rounding of acos"
+    rng = np.random.default_rng(5)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    fv = A.make_bow_feat_vec({i: [i] for i in range(n)})
+    E12 = np.ascontiguousarray(np.eye(3))
+    epipole = np.array([1.0, 0.0, 0.0])
+    res = []
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        pairs = np.zeros((n, 2), dtype=np.uint32)
+        num = C.c_uint32(0)
+        rc = getattr(lib_, prefix + "match_for_triangulation")(fv.ref(), A.ptr(d, A.u8p), A.ptr(k1, A.kpp), A.ptr(b1, A.f64p), None, None, n,
+                                                               fv.ref(), A.ptr(d, A.u8p), A.ptr(k2, A.kpp), A.ptr(b2, A.f64p), None, None, n,
+                                                               A.ptr(E12, A.f64p), A.ptr(epipole, A.f64p), A.ptr(sf, A.f32p), 8, 0,
+                                                               A.ptr(pairs, A.u32p), C.byref(num), *extra)
+        assert rc == 0
+        res.append((pairs[:num.value].copy(), num.value))
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+    assert 0 < res[0][1] < n
+
+
+def test_match_for_triangulation_last_of_equals_and_exclusion():
+    """robust.cc:102 keeps the LAST of equally distant candidates of a bucket, and a keypoint of
+    keyframe 2 serves one keypoint of keyframe 1 only (robust.cc:88,131): large buckets of identical
+    descriptors make both rules decide every match."""
+    rng = np.random.default_rng(9)
+    n, words = 600, 6
+    word = rng.integers(0, words, n)
+    centres = rng.integers(0, 256, (words, 32), dtype=np.uint8)
+    d1 = centres[word].copy()
+    d2 = centres[word].copy()
+    # a few bits of difference in part of the rows, so that distance ties are common but not universal
+    for i in rng.choice(n, n // 3, replace=False):
+        d2[i, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+    pts = np.column_stack([rng.uniform(-4, 4, n), rng.uniform(-3, 3, n), rng.uniform(4, 20, n)])
+    t21 = np.array([0.4, 0.0, 0.0])
+    b1, b2 = _unit(pts), _unit(pts + t21)
+    t12 = -t21
+    E12 = np.ascontiguousarray(np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]]))
+    epipole = _unit(t21[None, :])[0].copy()
+    k1 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k2 = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    k1["octave"] = 7  # the widest residual threshold: many candidates of a bucket are inliers
+    v = {}
+    for i in range(n):
+        v.setdefault(int(word[i]), []).append(i)
+    fv = A.make_bow_feat_vec(v)
+    sf = oracle.scale_table("scale_factors", 8, 1.2)
+    b1c, b2c = np.ascontiguousarray(b1), np.ascontiguousarray(b2)
+    res = []
+    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        pairs = np.zeros((n, 2), dtype=np.uint32)
+        num = C.c_uint32(0)
+        rc = getattr(lib_, prefix + "match_for_triangulation")(fv.ref(), A.ptr(d1, A.u8p), A.ptr(k1, A.kpp), A.ptr(b1c, A.f64p), None, None, n,
+                                                               fv.ref(), A.ptr(d2, A.u8p), A.ptr(k2, A.kpp), A.ptr(b2c, A.f64p), None, None, n,
+                                                               A.ptr(E12, A.f64p), A.ptr(epipole, A.f64p), A.ptr(sf, A.f32p), 8, 0,
+                                                               A.ptr(pairs, A.u32p), C.byref(num), *extra)
+        assert rc == 0
+        res.append((pairs[:num.value].copy(), num.value))
+    assert res[0][1] == res[1][1] and np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] > n // 4
