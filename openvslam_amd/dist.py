@@ -35,23 +35,44 @@ def merge_topk_host(lists, n_lists, nq):
     return out
 
 
-def sharded_search(local_search, queries, dist=None, device=None):
+def sharded_search(local_search, queries, dist=None, device=None, stream=None):
     """Top-2 over a database sharded across the ranks of `dist` (torch.distributed, already
-    initialised).  `local_search(queries) -> KNN2 array` searches this rank's shard and reports
-    GLOBAL row numbers.  Returns the merged result, identical on every rank.
+    initialised).  `local_search(queries)` searches this rank's shard and reports GLOBAL row numbers.
+    Returns the merged result (KNN2 array), identical on every rank.
 
-    With a CUDA/HIP `device` the exchange is an RCCL all-gather of a uint8 tensor on that device;
-    otherwise (CPU tests, gloo) the tensors stay on the host."""
+    With a CUDA/HIP `device` the whole exchange stays on that device: `local_search` may return its
+    result as a uint8 tensor on the device (the output buffer of ovs_desc_db_search_dev), the
+    per-shard lists travel in ONE RCCL all-gather and are merged by ovs_knn2_merge_dev.  Without a
+    device (CPU tests, gloo) `local_search` returns a numpy array and the merge runs on the host."""
     import torch
-    local = np.ascontiguousarray(local_search(queries), dtype=A.KNN2_DTYPE)
-    nq = len(local)
-    if dist is None or dist.get_world_size() == 1:
-        return merge_topk_host(local, 1, nq)
-    world = dist.get_world_size()
-    send = torch.from_numpy(local.view(np.uint8).reshape(-1).copy())
-    if device is not None:
-        send = send.to(device)
-    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=send.device)
-    dist.all_gather_into_tensor(recv, send)
-    gathered = recv.cpu().numpy().reshape(-1).view(A.KNN2_DTYPE).reshape(world, nq)
-    return merge_topk_host(gathered, world, nq)
+    local = local_search(queries)
+    world = 1 if dist is None else dist.get_world_size()
+    rec = np.dtype(A.KNN2_DTYPE).itemsize
+    if device is None:
+        local = np.ascontiguousarray(local, dtype=A.KNN2_DTYPE)
+        nq = len(local)
+        if world == 1:
+            return merge_topk_host(local, 1, nq)
+        send = torch.from_numpy(local.view(np.uint8).reshape(-1).copy())
+        recv = torch.empty(world * send.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)
+        return merge_topk_host(recv.numpy().reshape(-1).view(A.KNN2_DTYPE).reshape(world, nq), world, nq)
+    from ._lib import check, lib
+    if isinstance(local, torch.Tensor):
+        send = local.to(device).contiguous().view(torch.uint8).reshape(-1)
+    else:
+        send = torch.from_numpy(np.ascontiguousarray(local, dtype=A.KNN2_DTYPE).view(np.uint8).reshape(-1).copy()).to(device)
+    nq = send.numel() // rec
+    with torch.cuda.device(device):
+        if stream is None:
+            stream = torch.cuda.current_stream(device)
+        with torch.cuda.stream(stream):
+            if world > 1 or dist is not None:
+                recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
+                dist.all_gather_into_tensor(recv, send)
+            else:
+                recv = send
+            merged = torch.empty(nq * rec, dtype=torch.uint8, device=device)
+            check(lib().ovs_knn2_merge_dev(recv.data_ptr(), world, nq, merged.data_ptr(), stream.cuda_stream))
+        stream.synchronize()
+    return merged.cpu().numpy().view(A.KNN2_DTYPE).reshape(nq)

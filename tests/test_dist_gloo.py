@@ -80,3 +80,24 @@ def test_shard_partitions_cover_everything_once():
             for (f0, c0), (f1, _) in zip(parts, parts[1:]):
                 assert f0 + c0 == f1
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus N` without a torch.distributed environment starts N rank processes with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (before any GPU call: --dry-run needs no GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    ranks = [json.loads(line) for line in p.stderr.splitlines() if line.startswith("{")]
+    assert sorted(r["rank"] for r in ranks) == [0, 1, 2]
+    assert all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in ranks)
+    assert len({r["master"] for r in ranks}) == 1 and ranks[0]["master"].startswith("127.0.0.1:")
+    # a contradiction between --gpus and the environment is an error, not a silent single-rank run
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+    # a failing rank fails the run
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "nonsense"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0

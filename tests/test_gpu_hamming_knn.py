@@ -221,3 +221,47 @@ def test_full_size_database_shards_find_planted_neighbours():
     # oracle on the sample: per-shard results and the merge of the oracle's own lists
     want = ovd.merge_topk_host(want_sample, n_shards, len(sample))
     assert merged[sample].tobytes() == want.tobytes()
+
+
+def test_sharded_search_device_path_over_rccl_world_of_one():
+    """openvslam_amd.dist.sharded_search with a device: per-shard search on the device, the RCCL
+    all-gather (backend nccl, a world of one rank here) and ovs_knn2_merge_dev, against the oracle's
+    scan.  Few distinct byte values make equal distances common."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from openvslam_amd import dist as ovd
+    rng = np.random.default_rng(21)
+    db = rng.integers(0, 4, (60001, 32), dtype=np.uint8)
+    q = rng.integers(0, 4, (700, 32), dtype=np.uint8)
+    db[59999] = db[3]
+    q[0] = db[3]
+    want = oracle_search(db, 777, q)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    L = _lib.lib()
+    h = C.c_void_p()
+    try:
+        d_db = torch.from_numpy(db).to(dev)
+        d_q = torch.from_numpy(q).to(dev)
+        _lib.check(L.ovs_desc_db_create(0, C.byref(h)))
+        _lib.check(L.ovs_desc_db_attach_dev(h, d_db.data_ptr(), len(db), 777))
+
+        def local_search(_q):
+            out = torch.zeros(len(q) * 24, dtype=torch.uint8, device=dev)
+            _lib.check(L.ovs_desc_db_search_dev(h, d_q.data_ptr(), len(q), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+            return out
+        got = ovd.sharded_search(local_search, q, dist=dist, device=dev)
+        assert got.tobytes() == want.tobytes()
+        # host lists into the device path
+        got2 = ovd.sharded_search(lambda _q: db_search(db, 777, q), q, dist=dist, device=dev)
+        assert got2.tobytes() == want.tobytes()
+    finally:
+        if h:
+            L.ovs_desc_db_destroy(h)
+        dist.destroy_process_group()

@@ -147,20 +147,66 @@ def test_get_cell_indices_valid_cases_2():
                 assert _cell(g, x, y) == (1, ix, iy)
 
 
-def test_get_cell_indices_corners_and_invalid():
-    # valid_cases_1 / invalid_cases of the reference use a distorted camera whose bounds come from
-    # cv::undistortPoints; the same corner / edge pattern is applied to the undistorted bounds here
-    g = _cam_2000x1000()
-    eps = 0.01
-    assert _cell(g, g.min_x, g.min_y) == (1, 0, 0)
-    assert _cell(g, g.max_x - eps, g.min_y) == (1, 63, 0)
-    assert _cell(g, g.min_x, g.max_y - eps) == (1, 0, 47)
-    assert _cell(g, g.max_x - eps, g.max_y - eps) == (1, 63, 47)
-    assert _cell(g, 1000.0, g.min_y)[0:2] == (1, 32) or _cell(g, 1000.0, g.min_y)[0:2] == (1, 31)
-    for x, y in [(g.min_x - eps, g.min_y - eps), (g.max_x, g.min_y - eps), (g.min_x - eps, g.max_y),
-                 (g.max_x, g.max_y), (1000.0, g.min_y - eps), (1000.0, g.max_y), (g.min_x - eps, 500.0),
-                 (g.max_x, 500.0)]:
-        assert _cell(g, x, y)[0] == 0
+def distorted_camera_2000x1000():
+    """create_perspective_camera(2000, 1000, -0.1, 0.1) of the reference test (common_get_cell_indices.cc:8-14):
+    fx = fy = rows, cx = cols / 2, cy = rows / 2, k1 and k2 handed over as floats."""
+    cam = A.Camera()
+    cam.model = A.CAMERA_PERSPECTIVE
+    cam.cols, cam.rows = 2000, 1000
+    cam.fx = cam.fy = 1000.0
+    cam.cx, cam.cy = 1000.0, 500.0
+    for i, v in enumerate((float(np.float32(-0.1)), float(np.float32(0.1)), 0.0, 0.0, 0.0)):
+        cam.dist[i] = v
+    return cam
+
+
+def image_bounds_grid(undistort, cam):
+    """camera::perspective::compute_image_bounds (camera/perspective.cc:72-97) + the cell sizes of
+    perspective.cc:29-30: the four image corners are undistorted, the bounds are their extremes."""
+    corners = np.zeros(4, dtype=A.KEYPOINT_DTYPE)
+    corners["x"] = [0.0, cam.cols, 0.0, cam.cols]
+    corners["y"] = [0.0, 0.0, cam.rows, cam.rows]
+    corners["size"] = 1.0
+    und = undistort(cam, corners)
+    return A.make_grid(min(und["x"][0], und["x"][2]), min(und["y"][0], und["y"][1]),
+                       max(und["x"][1], und["x"][3]), max(und["y"][2], und["y"][3]))
+
+
+def cell_index_cases(g, cols=2000, rows=1000):
+    """valid_cases_1 (common_get_cell_indices.cc:16-57) and invalid_cases (:113-144): keypoint
+    coordinates (float arithmetic as in the C++ initialisers) and the expected cells."""
+    eps = np.float32(0.01)
+    f = np.float32
+    nc, nr = g.num_cols, g.num_rows
+    min_x, max_x, min_y, max_y = f(g.min_x), f(g.max_x), f(g.min_y), f(g.max_y)
+    valid = [((min_x, min_y), (0, 0)), ((max_x - eps, min_y), (nc - 1, 0)), ((min_x, max_y - eps), (0, nr - 1)),
+             ((max_x - eps, max_y - eps), (nc - 1, nr - 1)),
+             ((f(cols / 2.0), min_y), (nc // 2 - 1, 0)), ((f(cols / 2.0), max_y - eps), (nc // 2 - 1, nr - 1)),
+             ((min_x, f(rows / 2.0)), (0, nr // 2 - 1)), ((max_x - eps, f(rows / 2.0)), (nc - 1, nr // 2 - 1))]
+    invalid = [(min_x - eps, min_y - eps), (max_x, min_y - eps), (min_x - eps, max_y), (max_x, max_y),
+               (f(cols / 2.0), min_y - eps), (f(cols / 2.0), max_y), (min_x - eps, f(rows / 2.0)), (max_x, f(rows / 2.0))]
+    return valid, invalid
+
+
+def _oracle_undistort(cam, kps):
+    out = np.zeros(len(kps), dtype=A.KEYPOINT_DTYPE)
+    assert L.ovo_undistort_keypoints(C.byref(cam), A.ptr(kps, A.kpp), len(kps), A.ptr(out, A.kpp)) == 0
+    return out
+
+
+def test_get_cell_indices_distorted_camera_valid_and_invalid_cases():
+    """test/openvslam/data/common_get_cell_indices.cc:16-57,113-144 as written: the 2000 x 1000 camera
+    with k1 = -0.1, k2 = 0.1, whose image bounds come from undistorting the image corners.  The top
+    and bottom centre cases expect cell num_grid_cols / 2 - 1 = 31, which only holds because the
+    undistorted bounds are not exactly symmetric in float: the case pins the undistortion, too."""
+    cam = distorted_camera_2000x1000()
+    g = image_bounds_grid(_oracle_undistort, cam)
+    assert g.min_x > 0 and g.max_x < 2000 and g.min_y > 0 and g.max_y < 1000   # barrel model: the corners move inwards
+    valid, invalid = cell_index_cases(g)
+    for (x, y), (ix, iy) in valid:
+        assert _cell(g, x, y) == (1, ix, iy), (x, y)
+    for x, y in invalid:
+        assert _cell(g, x, y)[0] == 0, (x, y)
 
 
 # ---- OpenCV helper semantics ------------------------------------------------------------------
