@@ -275,6 +275,14 @@ int ovs_match_keyframe_one_way(const ovs_frame_view* keyfrm, const ovs_proj_quer
 int ovs_cross_check(const int32_t* idx2_of_1, int n1, const int32_t* idx1_of_2, int n2,
                     int32_t* out_idx2_of_1, uint32_t* num_matches);
 
+/* match::angle_checker<T>(30, num_bins_thr) (src/openvslam/match/angle_checker.h:60-134) on its own:
+ * append_delta_angle for each of the n delta angles (degrees), then is_valid[i] = 1 when entry i is
+ * among get_valid_matches() (its bin is one of the num_bins_thr fullest of the 30 bins, equally full
+ * bins ordered as std::sort of libstdc++ orders them), 0 when among get_invalid_matches().  Every
+ * matcher above runs this check inside its own kernels; this entry point exposes the class itself.
+ * A delta angle outside (-360, 720) gives OVS_ERR_OUT_OF_RANGE (angle_histogram_.at() throws). */
+int ovs_angle_checker_partition(const float* delta_angles, int n, int num_bins_thr, uint8_t* is_valid, int device);
+
 /* ------------------------------------------------------------------------------------------ */
 /* match::stereo                                                                              */
 /* ------------------------------------------------------------------------------------------ */

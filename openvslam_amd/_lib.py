@@ -84,6 +84,7 @@ def _declare(L):
     L.ovs_match_by_sim3_transform.argtypes = [fv, pq, A.u8p, C.c_float, A.i32p, A.u32p, i]
     L.ovs_match_keyframe_one_way.argtypes = [fv, pq, C.c_float, A.i32p, i]
     L.ovs_cross_check.argtypes = [A.i32p, i, A.i32p, i, A.i32p, A.u32p]
+    L.ovs_angle_checker_partition.argtypes = [A.f32p, i, i, A.u8p, i]
     iv = C.POINTER(A.ImageView)
     L.ovs_stereo_compute.argtypes = [iv, iv, i, A.kpp, i, A.kpp, i, A.u8p, A.u8p, A.f32p, A.f32p,
                                      C.c_float, C.c_float, A.f32p, A.f32p, i]

@@ -72,14 +72,12 @@ __global__ __launch_bounds__(256) void k_hamming_matrix(const uint8_t* __restric
 // lexicographic (distance, row) minimum, which equals the serial scan over all rows.
 constexpr int kKnnRowsPerBlock = 4096;
 
+// (selects, not branches: the compiler turns the branchy form into one store through a computed
+// address, which puts b0 / b1 into scratch memory)
 __device__ __forceinline__ void knn_push(u64 key, u64& b0, u64& b1) {
-    if (key < b0) {
-        b1 = b0;
-        b0 = key;
-    }
-    else if (key < b1) {
-        b1 = key;
-    }
+    const bool lt0 = key < b0, lt1 = key < b1;
+    b1 = lt0 ? b0 : (lt1 ? key : b1);
+    b0 = lt0 ? key : b0;
 }
 
 __global__ __launch_bounds__(256) void k_knn2_partial(const uint8_t* __restrict__ db, long long n_rows, const uint8_t* __restrict__ queries, int nq,
@@ -232,8 +230,9 @@ __global__ __launch_bounds__(256, kMmBlocksPerCu) void k_knn2_mfma(const uint8_t
         }
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
-            const u32 pair = (kq & 2) ? qd[2 * sidx + 1] : qd[2 * sidx];
-            const v4i e = expand16((pair >> (16 * (kq & 1))) & 0xFFFFu);
+            // halfword kq of the 64 bits of this k step (a shift: indexing qd by kq would put it in scratch memory)
+            const u64 bits64 = ((u64)qd[2 * sidx + 1] << 32) | qd[2 * sidx];
+            const v4i e = expand16((u32)(bits64 >> (16 * kq)) & 0xFFFFu);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bq[t][sidx][j] = qi < nq ? (int)~((u32)e[j] * 0xFEu) : 0;
@@ -386,12 +385,12 @@ __global__ __launch_bounds__(256) void k_knn2_finish(const u64* __restrict__ par
         knn_push(p[0], m0, m1);
         knn_push(p[1], m0, m1);
     }
-    ovs_knn2 r;
-    r.dist[0] = m0 == kNoKey ? kMaxDist : (u32)(m0 >> 48);
-    r.row[0] = m0 == kNoKey ? -1 : (long long)(m0 & 0xFFFFFFFFFFFFull) + row_offset;
-    r.dist[1] = m1 == kNoKey ? kMaxDist : (u32)(m1 >> 48);
-    r.row[1] = m1 == kNoKey ? -1 : (long long)(m1 & 0xFFFFFFFFFFFFull) + row_offset;
-    out[qi] = r;
+    // (field by field: a local struct copied as a whole goes through scratch memory)
+    ovs_knn2* o = out + qi;
+    o->dist[0] = m0 == kNoKey ? kMaxDist : (u32)(m0 >> 48);
+    o->dist[1] = m1 == kNoKey ? kMaxDist : (u32)(m1 >> 48);
+    o->row[0] = m0 == kNoKey ? -1 : (long long)(m0 & 0xFFFFFFFFFFFFull) + row_offset;
+    o->row[1] = m1 == kNoKey ? -1 : (long long)(m1 & 0xFFFFFFFFFFFFull) + row_offset;
 }
 
 __global__ __launch_bounds__(256) void k_knn2_merge(const ovs_knn2* __restrict__ lists, int n_lists, int nq, ovs_knn2* __restrict__ out) {
@@ -408,12 +407,11 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const ovs_knn2* __restrict__
             }
         }
     }
-    ovs_knn2 r;
-    r.dist[0] = m0 == kNoKey ? kMaxDist : (u32)(m0 >> 48);
-    r.row[0] = m0 == kNoKey ? -1 : (long long)(m0 & 0xFFFFFFFFFFFFull);
-    r.dist[1] = m1 == kNoKey ? kMaxDist : (u32)(m1 >> 48);
-    r.row[1] = m1 == kNoKey ? -1 : (long long)(m1 & 0xFFFFFFFFFFFFull);
-    out[qi] = r;
+    ovs_knn2* o = out + qi;
+    o->dist[0] = m0 == kNoKey ? kMaxDist : (u32)(m0 >> 48);
+    o->dist[1] = m1 == kNoKey ? kMaxDist : (u32)(m1 >> 48);
+    o->row[0] = m0 == kNoKey ? -1 : (long long)(m0 & 0xFFFFFFFFFFFFull);
+    o->row[1] = m1 == kNoKey ? -1 : (long long)(m1 & 0xFFFFFFFFFFFFull);
 }
 
 
@@ -621,6 +619,55 @@ int ovs_desc_db_attach_dev(ovs_desc_db* db, const uint8_t* d_descs, int64_t n_ro
     return OVS_OK;
 }
 
+namespace {
+// launch plan of a search: which kernel, how the rows are cut into slices
+struct knn_plan {
+    bool mfma;
+    int slices, rows_per_slice;
+    size_t partial_bytes;
+};
+
+knn_plan plan_search(const ovs_desc_db* db, int nq) {
+    knn_plan p;
+    // 128 queries and more: matrix-core kernel, row slices sized so that the grid is about two
+    // workgroups per compute unit (long slices keep the per-lane best / second best warm)
+    p.mfma = nq >= 128 && db->n_rows > 0;
+    p.rows_per_slice = kKnnRowsPerBlock;
+    if (p.mfma) {
+        const int qblocks = (nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock;
+        const long long want = std::max<long long>(1, 256 * kMmBlocksPerCu / qblocks);
+        const long long by_rows = std::max<long long>(1, (db->n_rows + 1023) / 1024);
+        const long long ns = std::min(want, by_rows);
+        long long rps = (db->n_rows + ns - 1) / ns;
+        rps = std::min<long long>((rps + kMmRows - 1) / kMmRows * kMmRows, kMmMaxSliceRows);
+        p.rows_per_slice = static_cast<int>(rps);
+        p.slices = static_cast<int>((db->n_rows + rps - 1) / rps);
+    }
+    else {
+        p.slices = static_cast<int>(std::max<long long>(1, (db->n_rows + kKnnRowsPerBlock - 1) / kKnnRowsPerBlock));
+    }
+    p.partial_bytes = static_cast<size_t>(p.slices) * nq * 2 * sizeof(u64);
+    return p;
+}
+
+// `partial`: plan.partial_bytes of device memory, fully written by the search kernel before the
+// finish kernel reads it (nothing has to be cleared)
+int launch_search(const ovs_desc_db* db, const knn_plan& plan, const uint8_t* d_queries, int nq, u64* partial, ovs_knn2* d_out, hipStream_t st) {
+    if (plan.mfma) {
+        OVS_LAUNCH("k_knn2_mfma", k_knn2_mfma, dim3((nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock, plan.slices), dim3(256), 0, st,
+                   db->d_rows, db->n_rows, plan.rows_per_slice, d_queries, nq, partial);
+    }
+    else {
+        OVS_LAUNCH("k_knn2_partial", k_knn2_partial, dim3((nq + 63) / 64, plan.slices), dim3(256), 0, st,
+                   db->d_rows, db->n_rows, d_queries, nq, partial);
+    }
+    OVS_LAUNCH("k_knn2_finish", k_knn2_finish, dim3((nq + 255) / 256), dim3(256), 0, st,
+               partial, plan.slices, nq, db->row_offset, d_out);
+    OVS_HIP(hipGetLastError());
+    return OVS_OK;
+}
+} // namespace
+
 int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream_) {
     if (!db || nq < 0 || (nq > 0 && (!d_queries || !d_out))) {
         return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
@@ -629,40 +676,12 @@ int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ov
         return OVS_OK;
     }
     ovs::device_guard guard(db->device);
-    hipStream_t st = static_cast<hipStream_t>(stream_);
-    // 128 queries and more: matrix-core kernel, row slices sized so that the grid is about two
-    // workgroups per compute unit (long slices keep the per-lane best / second best warm)
-    const bool mfma = nq >= 128 && db->n_rows > 0;
-    int slices, rows_per_slice = kKnnRowsPerBlock;
-    if (mfma) {
-        const int qblocks = (nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock;
-        const long long want = std::max<long long>(1, 256 * kMmBlocksPerCu / qblocks);
-        const long long by_rows = std::max<long long>(1, (db->n_rows + 1023) / 1024);
-        const long long ns = std::min(want, by_rows);
-        long long rps = (db->n_rows + ns - 1) / ns;
-        rps = std::min<long long>((rps + kMmRows - 1) / kMmRows * kMmRows, kMmMaxSliceRows);
-        rows_per_slice = static_cast<int>(rps);
-        slices = static_cast<int>((db->n_rows + rps - 1) / rps);
-    }
-    else {
-        slices = static_cast<int>(std::max<long long>(1, (db->n_rows + kKnnRowsPerBlock - 1) / kKnnRowsPerBlock));
-    }
-    int rc = db->partial.reserve(static_cast<size_t>(slices) * nq * 2 * sizeof(u64));
+    const knn_plan plan = plan_search(db, nq);
+    int rc = db->partial.reserve(plan.partial_bytes);
     if (rc != OVS_OK) {
         return rc;
     }
-    if (mfma) {
-        OVS_LAUNCH("k_knn2_mfma", k_knn2_mfma, dim3((nq + kMmQueriesPerBlock - 1) / kMmQueriesPerBlock, slices), dim3(256), 0, st,
-                   db->d_rows, db->n_rows, rows_per_slice, d_queries, nq, db->partial.as<u64>());
-    }
-    else {
-        OVS_LAUNCH("k_knn2_partial", k_knn2_partial, dim3((nq + 63) / 64, slices), dim3(256), 0, st,
-                   db->d_rows, db->n_rows, d_queries, nq, db->partial.as<u64>());
-    }
-    OVS_LAUNCH("k_knn2_finish", k_knn2_finish, dim3((nq + 255) / 256), dim3(256), 0, st,
-               db->partial.as<u64>(), slices, nq, db->row_offset, d_out);
-    OVS_HIP(hipGetLastError());
-    return OVS_OK;
+    return launch_search(db, plan, d_queries, nq, db->partial.as<u64>(), d_out, static_cast<hipStream_t>(stream_));
 }
 
 int ovs_desc_db_search(ovs_desc_db* db, const uint8_t* queries, int nq, ovs_knn2* out) {

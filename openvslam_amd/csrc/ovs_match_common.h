@@ -115,32 +115,62 @@ __device__ __forceinline__ int angle_bin(float delta_angle) {
 }
 
 // ---- host plumbing ----------------------------------------------------------------------------------
-// One growable scratch arena per (host thread, device, caller stream), plus one internal stream per
-// (host thread, device) for the entry points that take host buffers.  The matcher entry points keep
-// no other state, so they can be called from the tracking, mapping and global optimisation threads
+// One growable scratch arena per (host thread, device, caller stream) for the device-pointer entry
+// points, plus one internal context per (host thread, device) -- its own stream, arena and page-locked
+// mirror -- for the entry points that take host buffers.  The matcher entry points keep no other
+// state, so they can be called from the tracking, mapping and global optimisation threads
 // concurrently, and the device-pointer entry points may be in flight on several caller streams at
-// once: work queued on one stream never shares scratch memory with work queued on another.
+// once: work queued on one stream never shares scratch memory with work queued on another.  A caller
+// that passes the null stream gets a context of its own as well (the internal context is not the
+// null stream's: the internal stream is non-blocking and not ordered against it).
 struct thread_ctx {
     int device = -1;
-    hipStream_t key = nullptr;    // caller stream this context belongs to; nullptr = internal stream
-    hipStream_t stream = nullptr; // internal stream (key == nullptr only)
+    bool internal = false;        // the context of the host-buffer entry points
+    hipStream_t key = nullptr;    // caller stream this context belongs to (internal == false)
+    hipStream_t stream = nullptr; // internal stream (internal == true)
     ovs::dev_buffer arena;
     ovs::pinned_buffer mirror; // page-locked image of the arena, see host_stager
 };
 
-inline thread_ctx* ctx_for(int device, hipStream_t key = nullptr) {
-    static thread_local std::vector<thread_ctx*> ctxs; // pointers stay valid when the vector grows
-    for (thread_ctx* c : ctxs) {
-        if (c->device == device && c->key == key) {
+// The contexts of a host thread; released when the thread ends (its streams are drained first).
+struct thread_ctx_list {
+    std::vector<thread_ctx*> ctxs; // pointers stay valid when the vector grows
+    ~thread_ctx_list() {
+        for (thread_ctx* c : ctxs) {
+            int prev = -1;
+            if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(c->device) == hipSuccess) {
+                if (c->stream) {
+                    (void)hipStreamSynchronize(c->stream);
+                    (void)hipStreamDestroy(c->stream);
+                }
+                c->arena.release(); // hipFree waits for work that still uses the memory
+                c->mirror.release();
+                (void)hipSetDevice(prev);
+            }
+            delete c;
+        }
+    }
+};
+
+inline thread_ctx* ctx_lookup(int device, bool internal, hipStream_t key) {
+    static thread_local thread_ctx_list list;
+    for (thread_ctx* c : list.ctxs) {
+        if (c->device == device && c->internal == internal && c->key == key) {
             return c;
         }
     }
     thread_ctx* c = new thread_ctx;
     c->device = device;
+    c->internal = internal;
     c->key = key;
-    ctxs.push_back(c);
+    list.ctxs.push_back(c);
     return c;
 }
+
+// context of the host-buffer entry points
+inline thread_ctx* ctx_for(int device) { return ctx_lookup(device, true, nullptr); }
+// context of work the caller enqueues on `stream` (the null stream included)
+inline thread_ctx* ctx_for_stream(int device, hipStream_t stream) { return ctx_lookup(device, false, stream); }
 
 struct carver {
     uint8_t* base = nullptr;

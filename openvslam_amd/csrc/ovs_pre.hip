@@ -416,7 +416,7 @@ int ovs_equalize_histogram_dev(uint8_t* d_img, int n_frames, int width, int heig
     }
     ovs::device_guard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    thread_ctx* ctx = ctx_for(device, st);
+    thread_ctx* ctx = ctx_for_stream(device, st);
     const size_t hist_bytes = static_cast<size_t>(n_frames) * 256 * sizeof(u32);
     if ((rc = ctx->arena.reserve(al(hist_bytes))) != OVS_OK) {
         return rc;
@@ -447,7 +447,7 @@ int ovs_equalize_histogram_u16_dev(const uint16_t* d_img, int n_frames, int widt
     }
     ovs::device_guard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    thread_ctx* ctx = ctx_for(device, st);
+    thread_ctx* ctx = ctx_for_stream(device, st);
     const size_t hist_bytes = static_cast<size_t>(n_frames) * 65536 * sizeof(u32);
     if ((rc = ctx->arena.reserve(al(hist_bytes) + al(static_cast<size_t>(n_frames) * 2 * sizeof(int)))) != OVS_OK) {
         return rc;

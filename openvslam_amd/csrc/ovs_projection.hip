@@ -1255,6 +1255,43 @@ __global__ __launch_bounds__(256) void k_entries_from_list(const u32* __restrict
     g_desc[2 * j + 1] = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
+// match::angle_checker on its own (angle_checker.h:60-134): the rotation histogram of n delta angles
+// and, per entry, whether its bin is among the num_bins_thr fullest.  One wavefront; the same
+// angle_bin / index_sort_by_size code the resolve kernels run.
+__global__ __launch_bounds__(64) void k_angle_partition(const float* __restrict__ delta_angles, int n, int num_bins_thr,
+                                                        uint8_t* __restrict__ is_valid, int* __restrict__ err) {
+    __shared__ u32 hist[32];
+    __shared__ u32 order[32];
+    __shared__ ovs_sort::sort_frame sort_stack[ovs_sort::kSortStackEntries];
+    const int lane = threadIdx.x;
+    if (lane < 32) {
+        hist[lane] = 0;
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) {
+        const int bin = angle_bin(delta_angles[i]);
+        if (bin < 0 || 30 <= bin) {
+            *err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) throws
+        }
+        else {
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    wave_sync();
+    if (lane == 0) {
+        ovs_sort::index_sort_by_size(hist, order, 30, sort_stack);
+    }
+    wave_sync();
+    for (int i = lane; i < n; i += 64) {
+        const int bin = angle_bin(delta_angles[i]);
+        bool ok = false;
+        for (int k = 0; k < num_bins_thr; ++k) {
+            ok |= (int)order[k] == bin;
+        }
+        is_valid[i] = ok ? 1 : 0;
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 // LDS plan of k_proj_resolve: the claim bitmap always lives in LDS; the per-keypoint `matched` and
 // `claim` arrays join it when everything fits in 150 KB (a workgroup is one wavefront and a launch
@@ -2167,6 +2204,52 @@ int ovs_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
     return OVS_OK;
 }
 
+int ovs_angle_checker_partition(const float* delta_angles, int n, int num_bins_thr, uint8_t* is_valid, int device) {
+    // match::angle_checker<T>(30, num_bins_thr): append_delta_angle for every entry, then
+    // get_valid_matches / get_invalid_matches (angle_checker.h:60-134)
+    if (n < 0 || num_bins_thr < 0 || 30 < num_bins_thr || (n > 0 && (!delta_angles || !is_valid))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument"); // assert(num_bins_thr_ <= histogram_length_), angle_checker.h:64
+    }
+    int rc = check_device(device);
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    if (n == 0) {
+        return OVS_OK;
+    }
+    ovs::device_guard guard(device);
+    thread_ctx* ctx = ctx_for(device);
+    if ((rc = ensure_stream(ctx)) != OVS_OK) {
+        return rc;
+    }
+    const size_t nn = n;
+    if ((rc = ctx->arena.reserve(al(nn * 4) + al(nn) + al(4))) != OVS_OK) {
+        return rc;
+    }
+    carver cv;
+    cv.base = ctx->arena.as<uint8_t>();
+    host_stager hs;
+    if ((rc = hs.init(ctx, ctx->stream)) != OVS_OK) {
+        return rc;
+    }
+    auto* d_ang = cv.take<float>(nn);
+    auto* d_valid = cv.take<uint8_t>(nn);
+    auto* d_err = cv.take<int>(1);
+    hs.put(d_ang, delta_angles, nn * 4);
+    hs.fill(d_err, 0, 4);
+    OVS_HIP(hs.upload());
+    OVS_LAUNCH("k_angle_partition", k_angle_partition, dim3(1), dim3(64), 0, ctx->stream, d_ang, n, num_bins_thr, d_valid, d_err);
+    OVS_HIP(hipGetLastError());
+    int err = 0;
+    hs.get(is_valid, d_valid, nn);
+    hs.get(&err, d_err, 4);
+    OVS_HIP(hs.download());
+    if (err != 0) {
+        return ovs::fail(err, "rotation bin out of range");
+    }
+    return OVS_OK;
+}
+
 int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_1,
                                 const ovs_keypoint* undist_keypts_1, const double* bearings_1,
                                 const float* stereo_x_right_1, const uint8_t* has_lm_1, int n1,
@@ -2359,7 +2442,7 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
     }
     ovs::device_guard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    thread_ctx* ctx = ctx_for(device, st);
+    thread_ctx* ctx = ctx_for_stream(device, st);
     const size_t F = n_frames, fc = F * cap;
     const size_t total = al(64 * 4) + al(F * (ncell + 1) * 4) + al(fc * 4) * 5 + al(fc * 16) + al(fc * 32) + al(fc) + al(fc * kTopK * 8)
                          + al(256) + al(F * sizeof(proj_problem));

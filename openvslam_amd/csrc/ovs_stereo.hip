@@ -597,7 +597,7 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
     }
     ovs::device_guard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    thread_ctx* ctx = ctx_for(device, st);
+    thread_ctx* ctx = ctx_for_stream(device, st);
     const int items_cap = row_items_bound(cap, sf, num_levels);
     const int rows = im.lh[0];
     const size_t total = al((static_cast<size_t>(rows) + 1) * 4) + al(static_cast<size_t>(items_cap) * 4) + al(static_cast<size_t>(cap) * 4) + al(256);
@@ -726,7 +726,7 @@ int ovs_stereo_compute_batch_dev(ovs_orb* left, ovs_orb* right, int n_pairs,
     }
     ovs::device_guard guard(device);
     hipStream_t st = static_cast<hipStream_t>(stream_);
-    thread_ctx* ctx = ctx_for(device, st);
+    thread_ctx* ctx = ctx_for_stream(device, st);
     const int items_cap = row_items_bound(cap, sf, num_levels);
     const int rows = im.lh[0];
     im.kp_stride = cap;

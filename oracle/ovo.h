@@ -106,6 +106,7 @@ void ovo_angle_checker_destroy(ovo_angle_checker* c);
 void ovo_angle_checker_append(ovo_angle_checker* c, float delta_angle, int match);
 int ovo_angle_checker_valid(const ovo_angle_checker* c, int* out, int cap);
 int ovo_angle_checker_invalid(const ovo_angle_checker* c, int* out, int cap);
+int ovo_angle_checker_partition(const float* delta_angles, int n, int num_bins_thr, uint8_t* is_valid);
 
 /* ---- data/common.{h,cc} ---- */
 int ovo_get_cell_indices(const ovs_grid* g, float x, float y, int* cell_x, int* cell_y);

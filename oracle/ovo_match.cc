@@ -228,6 +228,29 @@ int ovo_angle_checker_invalid(const ovo_angle_checker* c, int* out, int cap) {
     return static_cast<int>(v.size());
 }
 
+int ovo_angle_checker_partition(const float* delta_angles, int n, int num_bins_thr, uint8_t* is_valid) {
+    // angle_checker<int>(30, num_bins_thr) with the entry number as the match (angle_checker.h:60-134)
+    if (num_bins_thr < 0 || 30 < num_bins_thr) {
+        return ovo::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    ovo::angle_checker checker(30, static_cast<unsigned int>(num_bins_thr));
+    try {
+        for (int i = 0; i < n; ++i) {
+            checker.append_delta_angle(delta_angles[i], i);
+        }
+    }
+    catch (const std::out_of_range&) {
+        return ovo::fail(OVS_ERR_OUT_OF_RANGE, "rotation bin out of range");
+    }
+    for (const int m : checker.get_valid_matches()) {
+        is_valid[m] = 1;
+    }
+    for (const int m : checker.get_invalid_matches()) {
+        is_valid[m] = 0;
+    }
+    return OVS_OK;
+}
+
 int ovo_get_cell_indices(const ovs_grid* g, float x, float y, int* cell_x, int* cell_y) {
     return ovo::get_cell_indices(*g, x, y, *cell_x, *cell_y) ? 1 : 0;
 }

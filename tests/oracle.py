@@ -87,6 +87,7 @@ def _declare(L):
     L.ovo_angle_checker_append.restype = None
     L.ovo_angle_checker_valid.argtypes = [C.c_void_p, A.i32p, i]
     L.ovo_angle_checker_invalid.argtypes = [C.c_void_p, A.i32p, i]
+    L.ovo_angle_checker_partition.argtypes = [A.f32p, i, i, A.u8p]
     L.ovo_get_cell_indices.argtypes = [C.POINTER(A.Grid), C.c_float, C.c_float, C.POINTER(i), C.POINTER(i)]
     fv = C.POINTER(A.FrameView)
     pq = C.POINTER(A.ProjQueries)

@@ -14,13 +14,20 @@ from openvslam_amd.feature import orb_extractor, orb_params
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("w,h,n_kp,n_frames", [(640, 480, 1000, 5), (1241, 376, 2000, 4)])
-def test_batch_extract_and_match(w, h, n_kp, n_frames):
+# the rectangle masks of the reference's tutorial configuration (docs/simple_tutorial.rst:297-301)
+TUTORIAL_RECTS = [(0.0, 1.0, 0.0, 0.1), (0.0, 1.0, 0.84, 1.0), (0.0, 0.2, 0.7, 1.0), (0.8, 1.0, 0.7, 1.0)]
+
+
+@pytest.mark.parametrize("w,h,n_kp,n_frames,rects", [(640, 480, 1000, 5, ()), (1241, 376, 2000, 4, ()),
+                                                     # the equirectangular configuration at full size: more than 8000
+                                                     # keypoint slots per frame, the resolve kernel's largest LDS plan
+                                                     (1920, 960, 4000, 3, TUTORIAL_RECTS)])
+def test_batch_extract_and_match(w, h, n_kp, n_frames, rects):
     dev = torch.device("cuda", 0)
     dx, dy = 3, 1
     frames = synth.make_sequence(w, h, n_frames, seed=77, dx=dx, dy=dy)
     d_frames = torch.from_numpy(frames).to(dev)
-    ext = orb_extractor(orb_params(max_num_keypts=n_kp), device=0)
+    ext = orb_extractor(orb_params(max_num_keypts=n_kp, mask_rects=rects), device=0)
     cap = ext.keypoint_capacity(w, h)
     kps = torch.zeros((n_frames, cap, 7), dtype=torch.float32, device=dev)
     desc = torch.zeros((n_frames, cap, 32), dtype=torch.uint8, device=dev)
@@ -44,7 +51,7 @@ def test_batch_extract_and_match(w, h, n_kp, n_frames):
     h_matched = matched.cpu().numpy()
     h_num = num.cpu().numpy()
 
-    ref = oracle.OrbExtractor(max_num_keypts=n_kp)
+    ref = oracle.OrbExtractor(max_num_keypts=n_kp, mask_rects=rects)
     r_kps = np.zeros((n_frames, cap), dtype=A.KEYPOINT_DTYPE)
     r_desc = np.zeros((n_frames, cap, 32), dtype=np.uint8)
     r_counts = np.zeros(n_frames, dtype=np.int32)
@@ -69,6 +76,10 @@ def test_batch_extract_and_match(w, h, n_kp, n_frames):
         n = r_counts[f]
         assert np.array_equal(h_matched[f, :n], r_matched[f, :n]), "frame %d matches differ" % f
     assert r_num[1:].min() > n_kp // 10
+    if rects:
+        # nothing inside the masked bands (test/openvslam/feature/orb_extractor.cc:212-217)
+        k = h_kps[0, :h_counts[0]]
+        assert k["y"].min() >= 0.1 * h - 1 and k["y"].max() <= 0.84 * h + 1
 
 
 @pytest.mark.parametrize("w,h,base_off,pad", [(641, 479, 1, 0), (1241, 376, 3, 5), (322, 247, 2, 1), (640, 480, 0, 0)])

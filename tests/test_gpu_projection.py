@@ -188,3 +188,24 @@ def test_greedy_conflicts_exhaust_candidate_lists():
     assert num == n  # every keypoint ends up claimed, each by a different query
     run_both("match_frame_and_keyframe", (view.ref(), q.ref(), None, 20.0, 100, 0), n)
     run_both("match_frame_and_landmarks", (view.ref(), q.ref(), None, 20.0, 0.8), n)
+
+
+@pytest.mark.parametrize("kind", ["current_and_last", "frame_and_landmarks", "sim3"])
+def test_searched_frame_beyond_the_lds_plan(kind):
+    """More keypoints in the searched frame (24 000) than the resolve kernel can keep per-keypoint state
+    for in LDS: its claim bookkeeping then lives in global memory and queries retire one per round."""
+    rng = np.random.default_rng(31)
+    n, nq, w, h = 24000, 9000, 4000.0, 3000.0
+    kps, desc, sxr = random_frame(rng, n, w=w, h=h, cluster=True)
+    xy, sl, qd, valid, xr, ang, has_obs = make_queries(rng, kps, desc, sxr, nq, jitter=3.0)
+    grid = A.make_grid(0.0, 0.0, w, h)
+    view = A.make_frame_view(kps, desc, SF, grid, sxr)
+    q = A.make_proj_queries(xy, sl, qd, valid, xr, ang, has_obs)
+    occupied = (rng.random(n) < 0.1).astype(np.uint8)
+    if kind == "current_and_last":
+        m, num = run_both("match_current_and_last_frames", (view.ref(), q.ref(), A.ptr(occupied, A.u8p), 20.0, A.DIR_NONE, 8, 0.9, 1), n)
+    elif kind == "frame_and_landmarks":
+        m, num = run_both("match_frame_and_landmarks", (view.ref(), q.ref(), A.ptr(occupied, A.u8p), 10.0, 0.8), n)
+    else:
+        m, num = run_both("match_by_sim3_transform", (view.ref(), q.ref(), A.ptr(occupied, A.u8p), 15.0), n)
+    assert num > 500

@@ -76,3 +76,65 @@ def test_equirectangular_4000_keypoints_with_tutorial_masks():
     k = both(img, mask, max_num_keypts=4000)   # an image mask overrides the rectangle mask
     assert len(k) >= 4000
     assert np.all((k["x"] - w // 2) ** 2 + (k["y"] - h // 2) ** 2 >= 199 ** 2)
+
+
+# ---- test/openvslam/match/angle_checker.cc:12-180 on the device --------------------------------------
+@pytest.mark.parametrize("thr,valid_set", [(1, {35}), (2, {35, 324}), (3, {35, 324, 127}), (30, {35, 324, 127, 0, 60, 180, 270})])
+def test_angle_checker_partitions_on_the_device(thr, valid_set):
+    """The reference's four partition cases (top 1 / 2 / 3 / all bins) through the device code of
+    match::angle_checker (the same histogram, bin rounding and sort the matcher kernels use)."""
+    import ctypes as C
+    from test_oracle_known_answers import ANGLE_CASES
+    from openvslam_amd import _abi as A
+    from openvslam_amd import _lib
+    angles = np.array([a for a, _ in ANGLE_CASES], dtype=np.float32)
+    matches = [m for _, m in ANGLE_CASES]
+    flags = np.full(len(angles), 7, dtype=np.uint8)
+    _lib.check(_lib.lib().ovs_angle_checker_partition(A.ptr(angles, A.f32p), len(angles), thr, A.ptr(flags, A.u8p), 0))
+    valid = {m for m, f in zip(matches, flags) if f == 1}
+    invalid = {m for m, f in zip(matches, flags) if f == 0}
+    assert set(flags.tolist()) <= {0, 1}
+    assert valid == valid_set and invalid == {35, 324, 127, 0, 60, 180, 270} - valid_set
+
+
+@pytest.mark.parametrize("seed,n", [(1, 500), (2, 31), (3, 5000)])
+def test_angle_checker_random_against_oracle(seed, n):
+    """Equally full bins are common here: the order std::sort leaves them in decides the partition."""
+    from openvslam_amd import _abi as A
+    from openvslam_amd import _lib
+    rng = np.random.default_rng(seed)
+    angles = (rng.integers(0, 12, n) * 30 + rng.uniform(-14, 14, n)).astype(np.float32)
+    angles[rng.random(n) < 0.2] -= 360.0
+    for thr in (1, 3, 7):
+        got = np.full(n, 7, dtype=np.uint8)
+        want = np.full(n, 9, dtype=np.uint8)
+        _lib.check(_lib.lib().ovs_angle_checker_partition(A.ptr(angles, A.f32p), n, thr, A.ptr(got, A.u8p), 0))
+        oracle.check(oracle.lib().ovo_angle_checker_partition(A.ptr(angles, A.f32p), n, thr, A.ptr(want, A.u8p)))
+        assert np.array_equal(got, want)
+
+
+# ---- test/openvslam/data/common_get_cell_indices.cc:16-57,113-144 on the device -----------------------
+def test_get_cell_indices_distorted_camera_on_the_device():
+    """The reference's distorted 2000 x 1000 camera: image bounds from the DEVICE undistortion of the
+    image corners (camera/perspective.cc:72-97), then the valid and invalid keypoint cases."""
+    import ctypes as C
+    from test_oracle_known_answers import cell_index_cases, distorted_camera_2000x1000, image_bounds_grid
+    from openvslam_amd import _abi as A
+    from openvslam_amd import _lib
+    L = _lib.lib()
+
+    def undistort(cam, kps):
+        out = np.zeros(len(kps), dtype=A.KEYPOINT_DTYPE)
+        _lib.check(L.ovs_undistort_keypoints(C.byref(cam), A.ptr(kps, A.kpp), len(kps), A.ptr(out, A.kpp), 0))
+        return out
+    g = image_bounds_grid(undistort, distorted_camera_2000x1000())
+    valid, invalid = cell_index_cases(g)
+
+    def cell(x, y):
+        cx, cy = C.c_int(-1), C.c_int(-1)
+        found = L.ovs_get_cell_indices(C.byref(g), np.float32(x), np.float32(y), C.byref(cx), C.byref(cy))
+        return found, cx.value, cy.value
+    for (x, y), (ix, iy) in valid:
+        assert cell(x, y) == (1, ix, iy), (x, y)
+    for x, y in invalid:
+        assert cell(x, y)[0] == 0, (x, y)
