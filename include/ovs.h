@@ -432,6 +432,17 @@ typedef struct ovs_knn2 {
 int ovs_desc_db_search(ovs_desc_db* db, const uint8_t* queries, int nq, ovs_knn2* out);
 /* Device buffers, enqueued on `stream`. */
 int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream);
+/* The search for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments and results as ovs_desc_db_search_dev; the per-slice partial results live in a 4 MiB array
+ * that is part of the library's code object (one copy per GPU, held until the process ends) instead of
+ * a buffer the call would have to grow.  A search whose slices x nq x 16 bytes exceed 4 MiB returns
+ * OVS_ERR_CAPACITY: that cannot happen with 128 queries or more (matrix-core kernel, at most 196 608
+ * partial entries); with fewer queries (popcount kernel, one slice per 4096 rows) it happens when
+ * ceil(rows / 4096) x nq exceeds 262 144.  The call makes no hipMalloc / hipFree; the array's address is
+ * looked up when the database handle is created.  All calls on one GPU share the array: calls that
+ * overlap on one GPU (different streams or threads) race on it. */
+int ovs_desc_db_search_noalloc_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream);
 /* Merges n_lists per-shard results (list-major: lists[s*nq + q]) into out[q] with the
  * lexicographic (dist, row) order, i.e. the serial strict-< scan over the whole database. */
 int ovs_knn2_merge(const ovs_knn2* lists, int n_lists, int nq, ovs_knn2* out);

@@ -129,6 +129,7 @@ def _declare(L):
     L.ovs_desc_db_attach_dev.argtypes = [vp, vp, C.c_int64, C.c_int64]
     L.ovs_desc_db_search.argtypes = [vp, A.u8p, i, A.knn2p]
     L.ovs_desc_db_search_dev.argtypes = [vp, vp, i, vp, vp]
+    L.ovs_desc_db_search_noalloc_dev.argtypes = [vp, vp, i, vp, vp]
     L.ovs_knn2_merge.argtypes = [A.knn2p, i, i, A.knn2p]
     L.ovs_knn2_merge_dev.argtypes = [vp, i, i, vp, vp]
     L.ovs_match_batch_current_and_last_dev.argtypes = [vp, vp, vp, i, i, vp, C.POINTER(A.Grid), A.f32p, i,

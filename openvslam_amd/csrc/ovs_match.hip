@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 using namespace ovsm;
@@ -491,6 +492,39 @@ __global__ __launch_bounds__(64) void k_landmark_median(const uint8_t* __restric
 
 } // namespace
 
+// ---- scratch memory of the entry point that allocates nothing -----------------------------------------
+// ovs_desc_db_search_noalloc_dev keeps the per-slice partial results of a search in this array instead
+// of a buffer from hipMalloc.  Every GPU the library runs on holds its own copy of the array (at its own
+// address) until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: the address kernels are given is looked up once per device, with that device
+// current, and kept in g_scratch_ptr.
+constexpr size_t kNoAllocScratchBytes = 4u << 20;
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+namespace {
+constexpr int kMaxScratchDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+
+// address of this device's copy of `scratch`; `device` must be the current device
+int scratch_for_device(int device, void** out) {
+    if (device < 0 || device >= kMaxScratchDevices) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "device ordinal beyond the scratch table");
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        OVS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) {
+            return ovs::fail(OVS_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        }
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return OVS_OK;
+}
+} // namespace
+
 struct ovs_desc_db {
     int device = 0;
     ovs::dev_buffer own;
@@ -569,6 +603,14 @@ int ovs_desc_db_create(int device, ovs_desc_db** out) {
     int rc = check_device(device);
     if (rc != OVS_OK) {
         return rc;
+    }
+    {
+        // set-up of the entry point that allocates nothing: this device's address of `scratch`
+        ovs::device_guard guard(device);
+        void* p = nullptr;
+        if ((rc = scratch_for_device(device, &p)) != OVS_OK) {
+            return rc;
+        }
     }
     auto* db = new ovs_desc_db();
     db->device = device;
@@ -682,6 +724,27 @@ int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ov
         return rc;
     }
     return launch_search(db, plan, d_queries, nq, db->partial.as<u64>(), d_out, static_cast<hipStream_t>(stream_));
+}
+
+int ovs_desc_db_search_noalloc_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream_) {
+    if (!db || nq < 0 || (nq > 0 && (!d_queries || !d_out))) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if (nq == 0) {
+        return OVS_OK;
+    }
+    ovs::device_guard guard(db->device);
+    const knn_plan plan = plan_search(db, nq);
+    if (plan.partial_bytes > kNoAllocScratchBytes) {
+        return ovs::fail(OVS_ERR_CAPACITY, "ovs_desc_db_search_noalloc_dev: this search needs more than the 4 MiB of built-in scratch memory "
+                                           "(slices x queries x 16 bytes); use ovs_desc_db_search_dev");
+    }
+    void* partial = nullptr;
+    int rc = scratch_for_device(db->device, &partial); // looked up at ovs_desc_db_create; a table read here
+    if (rc != OVS_OK) {
+        return rc;
+    }
+    return launch_search(db, plan, d_queries, nq, static_cast<u64*>(partial), d_out, static_cast<hipStream_t>(stream_));
 }
 
 int ovs_desc_db_search(ovs_desc_db* db, const uint8_t* queries, int nq, ovs_knn2* out) {

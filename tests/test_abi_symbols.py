@@ -55,7 +55,7 @@ def test_oracle_mirrors_the_compute_entry_points():
                "ovs_equalize_histogram_u16_dev": "ovo_equalize_histogram", "ovs_remap_apply_dev": "ovo_remap_linear",
                "ovs_remap_apply": "ovo_remap_linear",
                "ovs_desc_db_search": "ovo_knn2_search",
-               "ovs_desc_db_search_dev": "ovo_knn2_search", "ovs_knn2_merge_dev": "ovo_knn2_merge",
+               "ovs_desc_db_search_dev": "ovo_knn2_search", "ovs_desc_db_search_noalloc_dev": "ovo_knn2_search", "ovs_knn2_merge_dev": "ovo_knn2_merge",
                "ovs_match_batch_current_and_last_dev": "ovo_match_batch_current_and_last",
                "ovs_convert_keypoints_to_bearings_dev": "ovo_convert_keypoints_to_bearings",
                "ovs_undistort_keypoints_dev": "ovo_undistort_keypoints"}
