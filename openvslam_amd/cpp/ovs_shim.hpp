@@ -207,8 +207,14 @@ public:
         const bool has_mask = !mt::empty(in_image_mask);
         check(ovs_orb_extract(h_, mt::data(in_image), w, h, mt::step(in_image), has_mask ? mt::data(in_image_mask) : nullptr,
                               has_mask ? mt::step(in_image_mask) : 0, kps_.data(), desc_.data(), cap, &n));
-        // image_pyramid_ is public in the reference and read by match::stereo after extract()
-        image_pyramid_.resize(get_num_scale_levels());
+        // image_pyramid_ is public in the reference and read by match::stereo after extract(): here
+        // its entries name the levels that stay on the device inside this extractor
+        image_pyramid_.assign(get_num_scale_levels(), plane());
+        for (unsigned int lv = 0; lv < image_pyramid_.size(); ++lv) {
+            image_pyramid_[lv].owner = this;
+            image_pyramid_[lv].level = lv;
+            check(ovs_orb_level_size(h_, w, h, static_cast<int>(lv), &image_pyramid_[lv].width, &image_pyramid_[lv].height));
+        }
         keypts.resize(static_cast<size_t>(n));
         if (n == 0) {
             mt::release(out_descriptors);
@@ -240,10 +246,14 @@ public:
     std::vector<float> get_level_sigma_sq() const { return table(ovs_orb_get_level_sigma_sq); }
     std::vector<float> get_inv_level_sigma_sq() const { return table(ovs_orb_get_inv_level_sigma_sq); }
 
-    // Host copy of one level of image_pyramid_ of the last extract() (level 0 is the caller's image).
+    // One level of image_pyramid_.  The entries of image_pyramid_ itself carry no pixels: they name a
+    // level resident on the device (owner, level); image_pyramid_level() returns a host copy with pixels
+    // (level 0 is the caller's image).
     struct plane {
         std::vector<uint8_t> pixels;
         int width = 0, height = 0;
+        orb_extractor* owner = nullptr;
+        unsigned int level = 0;
     };
     plane image_pyramid_level(unsigned int level) {
         plane pl;
@@ -1125,19 +1135,103 @@ private:
     }
 };
 
-// match/stereo.h: constructed from the two extractors (whose image_pyramid_ the reference reads,
-// data/frame.cc:77), keypoints and descriptors.  The pyramids stay on the device inside the
-// extractor handles; compute() must run before either extractor extracts again, as in the
-// reference's frame constructor.
+// match/stereo.h.  Three ways to name the two image pyramids:
+//   * the reference's argument list (stereo.h:18-22) with the extractors' image_pyramid_ members, as
+//     data/frame.cc:77-81 writes it: the entries of image_pyramid_ name levels that are still on the
+//     device, so nothing but keypoints and descriptors travels (compute() must run before either
+//     extractor extracts again, as in the reference's frame constructor);
+//   * the same argument list with host images (std::vector of the caller's matrix type, cv::Mat in the
+//     reference tree): the pyramids are uploaded by ovs_stereo_compute;
+//   * the two extractors themselves.
 class stereo {
 public:
+    stereo() = delete;
+
     template <class KeyPoint, class Mat>
     stereo(feature::orb_extractor& left, feature::orb_extractor& right, const std::vector<KeyPoint>& keypts_left,
            const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right,
            const std::vector<float>& scale_factors, const std::vector<float>& inv_scale_factors,
            const float focal_x_baseline, const float true_baseline, int device = 0)
-        : left_(left), right_(right), scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors),
+        : left_(&left), right_(&right), scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors),
           focal_x_baseline_(focal_x_baseline), true_baseline_(true_baseline), device_(device) {
+        take(keypts_left, keypts_right, descs_left, descs_right);
+    }
+
+    // stereo.h:18-22 with left_image_pyramid = extractor_left->image_pyramid_ (resident levels), or with
+    // planes that hold pixels (image_pyramid_level() copies)
+    template <class KeyPoint, class Mat>
+    stereo(const std::vector<feature::orb_extractor::plane>& left_image_pyramid, const std::vector<feature::orb_extractor::plane>& right_image_pyramid,
+           const std::vector<KeyPoint>& keypts_left, const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right,
+           const std::vector<float>& scale_factors, const std::vector<float>& inv_scale_factors,
+           const float focal_x_baseline, const float true_baseline, int device = 0)
+        : scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors),
+          focal_x_baseline_(focal_x_baseline), true_baseline_(true_baseline), device_(device) {
+        if (left_image_pyramid.size() != right_image_pyramid.size() || left_image_pyramid.empty()) {
+            throw std::runtime_error("match::stereo: the two image pyramids must have the same, non-zero number of levels");
+        }
+        const bool resident = left_image_pyramid[0].owner && right_image_pyramid[0].owner && left_image_pyramid[0].pixels.empty()
+                              && right_image_pyramid[0].pixels.empty();
+        if (resident) {
+            left_ = left_image_pyramid[0].owner;
+            right_ = right_image_pyramid[0].owner;
+        }
+        else {
+            for (size_t lv = 0; lv < left_image_pyramid.size(); ++lv) {
+                const feature::orb_extractor::plane &l = left_image_pyramid[lv], &r = right_image_pyramid[lv];
+                if (l.pixels.size() != static_cast<size_t>(l.width) * l.height || r.pixels.size() != static_cast<size_t>(r.width) * r.height) {
+                    throw std::runtime_error("match::stereo: pyramid level without pixels");
+                }
+                pyr_l_.push_back(ovs_image_view{l.pixels.data(), l.width, l.height, static_cast<size_t>(l.width)});
+                pyr_r_.push_back(ovs_image_view{r.pixels.data(), r.width, r.height, static_cast<size_t>(r.width)});
+            }
+        }
+        take(keypts_left, keypts_right, descs_left, descs_right);
+    }
+
+    // stereo.h:18-22 with host images (the caller keeps them alive until compute() returns, as the
+    // reference's cv::Mat headers keep theirs)
+    template <class Img, class KeyPoint, class Mat>
+    stereo(const std::vector<Img>& left_image_pyramid, const std::vector<Img>& right_image_pyramid,
+           const std::vector<KeyPoint>& keypts_left, const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right,
+           const std::vector<float>& scale_factors, const std::vector<float>& inv_scale_factors,
+           const float focal_x_baseline, const float true_baseline, int device = 0)
+        : scale_factors_(scale_factors), inv_scale_factors_(inv_scale_factors),
+          focal_x_baseline_(focal_x_baseline), true_baseline_(true_baseline), device_(device) {
+        if (left_image_pyramid.size() != right_image_pyramid.size() || left_image_pyramid.empty()) {
+            throw std::runtime_error("match::stereo: the two image pyramids must have the same, non-zero number of levels");
+        }
+        typedef mat_traits<Img> it;
+        for (size_t lv = 0; lv < left_image_pyramid.size(); ++lv) {
+            const Img &l = left_image_pyramid[lv], &r = right_image_pyramid[lv];
+            pyr_l_.push_back(ovs_image_view{it::data(l), it::cols(l), it::rows(l), it::step(l)});
+            pyr_r_.push_back(ovs_image_view{it::data(r), it::cols(r), it::rows(r), it::step(r)});
+        }
+        take(keypts_left, keypts_right, descs_left, descs_right);
+    }
+
+    virtual ~stereo() = default;
+
+    // stereo.cc:18-113
+    void compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
+        stereo_x_right.assign(kl_.size(), -1.0f);
+        depths.assign(kl_.size(), -1.0f);
+        if (left_ && right_) {
+            check(ovs_stereo_compute_resident(left_->handle(), right_->handle(), kl_.data(), static_cast<int>(kl_.size()), kr_.data(),
+                                              static_cast<int>(kr_.size()), dl_.data(), dr_.data(), focal_x_baseline_, true_baseline_,
+                                              stereo_x_right.data(), depths.data(), device_));
+            return;
+        }
+        if (scale_factors_.size() < pyr_l_.size() || inv_scale_factors_.size() < pyr_l_.size()) {
+            throw std::runtime_error("match::stereo: scale factor tables shorter than the image pyramid");
+        }
+        check(ovs_stereo_compute(pyr_l_.data(), pyr_r_.data(), static_cast<int>(pyr_l_.size()), kl_.data(), static_cast<int>(kl_.size()),
+                                 kr_.data(), static_cast<int>(kr_.size()), dl_.data(), dr_.data(), scale_factors_.data(), inv_scale_factors_.data(),
+                                 focal_x_baseline_, true_baseline_, stereo_x_right.data(), depths.data(), device_));
+    }
+
+private:
+    template <class KeyPoint, class Mat>
+    void take(const std::vector<KeyPoint>& keypts_left, const std::vector<KeyPoint>& keypts_right, const Mat& descs_left, const Mat& descs_right) {
         static_assert(sizeof(KeyPoint) == sizeof(ovs_keypoint), "cv::KeyPoint layout expected");
         kl_.resize(keypts_left.size());
         kr_.resize(keypts_right.size());
@@ -1150,21 +1244,12 @@ public:
         for (size_t i = 0; i < kr_.size(); ++i) std::memcpy(dr_.data() + 32 * i, mt::data(descs_right) + mt::step(descs_right) * i, 32);
     }
 
-    // stereo.cc:18-113
-    void compute(std::vector<float>& stereo_x_right, std::vector<float>& depths) const {
-        stereo_x_right.assign(kl_.size(), -1.0f);
-        depths.assign(kl_.size(), -1.0f);
-        check(ovs_stereo_compute_resident(left_.handle(), right_.handle(), kl_.data(), static_cast<int>(kl_.size()), kr_.data(),
-                                          static_cast<int>(kr_.size()), dl_.data(), dr_.data(), focal_x_baseline_, true_baseline_,
-                                          stereo_x_right.data(), depths.data(), device_));
-    }
-
-private:
-    feature::orb_extractor& left_;
-    feature::orb_extractor& right_;
+    feature::orb_extractor* left_ = nullptr;  // both set: the pyramids are resident in the two extractors
+    feature::orb_extractor* right_ = nullptr;
+    std::vector<ovs_image_view> pyr_l_, pyr_r_; // host pyramids otherwise
     std::vector<ovs_keypoint> kl_, kr_;
     std::vector<uint8_t> dl_, dr_;
-    const std::vector<float> scale_factors_, inv_scale_factors_; // kept for the signature; the handles hold the same tables
+    const std::vector<float> scale_factors_, inv_scale_factors_;
     const float focal_x_baseline_, true_baseline_;
     const int device_;
 };

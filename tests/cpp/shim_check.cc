@@ -336,7 +336,28 @@ int main(int argc, char** argv) {
             n_stereo_ok += std::fabs((frm[0].keypts_[i].x - sxr[i]) - dx) < 1.0f && std::fabs(sdepth[i] - 40.0f / (frm[0].keypts_[i].x - sxr[i])) < 1e-3f;
         }
     }
-    const bool stereo_ok = n_stereo > 200 && n_stereo_ok * 10 > n_stereo * 9;
+    bool stereo_ok = n_stereo > 200 && n_stereo_ok * 10 > n_stereo * 9;
+    {
+        // the reference's own argument list (match/stereo.h:18-22), as data/frame.cc:77-81 writes it: with the
+        // extractors' image_pyramid_ members (levels resident on the device) ...
+        std::vector<float> sxr2, sdepth2;
+        match::stereo(ext.image_pyramid_, ext_r.image_pyramid_, frm[0].keypts_, kps_r, frm[0].descriptors_, desc_r, ext.get_scale_factors(),
+                      ext.get_inv_scale_factors(), 40.0f, 0.5f).compute(sxr2, sdepth2);
+        stereo_ok = stereo_ok && sxr2 == sxr && sdepth2 == sdepth;
+        // ... and with host images: the pyramids travel with the call
+        std::vector<mock::mat_u8> pyr_l(ext.get_num_scale_levels()), pyr_r(ext.get_num_scale_levels());
+        for (unsigned int lv = 0; lv < pyr_l.size(); ++lv) {
+            const auto pl = ext.image_pyramid_level(lv), pr = ext_r.image_pyramid_level(lv);
+            pyr_l[lv].create(pl.height, pl.width);
+            pyr_r[lv].create(pr.height, pr.width);
+            std::memcpy(pyr_l[lv].data, pl.pixels.data(), pl.pixels.size());
+            std::memcpy(pyr_r[lv].data, pr.pixels.data(), pr.pixels.size());
+        }
+        std::vector<float> sxr3, sdepth3;
+        match::stereo(pyr_l, pyr_r, frm[0].keypts_, kps_r, frm[0].descriptors_, desc_r, ext.get_scale_factors(), ext.get_inv_scale_factors(),
+                      40.0f, 0.5f).compute(sxr3, sdepth3);
+        stereo_ok = stereo_ok && sxr3 == sxr && sdepth3 == sdepth;
+    }
     // brute force + (stand-in) essential-matrix inlier selection
     std::vector<mock::landmark*> robust_matched;
     const unsigned n_rkf = match::robust(0.75f, true).match_frame_and_keyframe<mock::row_solver>(frm[1], &frm[0], robust_matched);
