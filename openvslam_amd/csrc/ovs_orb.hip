@@ -29,6 +29,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <vector>
 
 namespace {
@@ -429,17 +431,12 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // so each flag is bit 8 of a 16-bit lane, i.e. the upper byte of the lane is 0 or 1.  One v_perm
 // collects the four flag bytes of a side in pixel order; the caller turns them into mask bits
 // with one v_dot4 per side.  `xd` / `xb`: byte p = 1 iff pixel c + p passed the dark / bright test.
-__device__ __forceinline__ void fast_quick_flags(const uint8_t* tile, int trow, int strip, pk16 cpk, u32& xd, u32& xb) {
-    // dwords strip, strip + 1, strip + 2 of a tile row hold columns c - 4 .. c + 7 (c = first pixel
-    // of the strip); selector bytes 0..3 address the second v_perm source, 4..7 the first, 0x0c = 0
-    const u32* r0 = reinterpret_cast<const u32*>(tile + trow * kTileStride) + strip;
-    const u32* rm2 = reinterpret_cast<const u32*>(tile + (trow - 2) * kTileStride) + strip;
-    const u32* rp2 = reinterpret_cast<const u32*>(tile + (trow + 2) * kTileStride) + strip;
-    const u32 up3 = reinterpret_cast<const u32*>(tile + (trow - 3) * kTileStride)[strip + 1];
-    const u32 dn3 = reinterpret_cast<const u32*>(tile + (trow + 3) * kTileStride)[strip + 1];
-    const u32 c0 = r0[0], c1 = r0[1], c2 = r0[2];
-    const u32 m0 = rm2[0], m1 = rm2[1], m2 = rm2[2];
-    const u32 p0 = rp2[0], p1 = rp2[1], p2 = rp2[2];
+// c0, c1, c2 / m0, m1, m2 / p0, p1, p2: the three dwords around the strip (columns c - 4 .. c + 7) of the
+// strip's row and of the rows two above and two below; up3 / dn3: the strip's own dword of the rows
+// three above and below.
+__device__ __forceinline__ void fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0, u32 m1, u32 m2, u32 p0, u32 p1, u32 p2, u32 up3, u32 dn3,
+                                                 pk16 cpk, u32& xd, u32& xb) {
+    // selector bytes 0..3 address the second v_perm source, 4..7 the first, 0x0c = 0
     constexpr u32 kEven = 0x0c020c00u, kOdd = 0x0c030c01u;       // (b0, b2), (b1, b3) of one dword
     constexpr u32 kB2nB0 = 0x0c040c02u, kB3nB1 = 0x0c050c03u;     // (lo.b2, hi.b0), (lo.b3, hi.b1)
     const pk16 ve = pick2(c1, c1, kEven), vo = pick2(c1, c1, kOdd);
@@ -466,23 +463,40 @@ __device__ __forceinline__ void fast_quick_flags(const uint8_t* tile, int trow, 
     xb = __builtin_amdgcn_perm(fbo, fbe, kFlagBytes);
 }
 
-// One side of the exact score for a pixel that passed the rejection test on that side.  `inv` is 0
-// for the dark side and 0xFF for the bright side (the bright test of x is the dark test of 255 - x).
-// Returns v' - min over the 16 arcs of 9 of the arc maximum, i.e. the largest t + 1 at which the
-// pixel is a corner on this side (or <= 0).
-__device__ __forceinline__ int fast_side_score(const uint8_t* c, int inv) {
+// The four dwords 2 * pair .. 2 * pair + 3 of a tile row (columns 8 * pair - 4 .. 8 * pair + 11 of the
+// cell interior) as two aligned 8-byte LDS reads.  The address of the second read passes through an
+// empty asm so that the compiler keeps two ds_read_b64 (which the LDS serves conflict free for the lane
+// layout of stage A) instead of pairing them into one ds_read2_b64 (32 banks, twice the cycles).
+// (`tile` must be the __shared__ array itself so that both reads stay LDS instructions; the opaque
+// value is the byte offset, not the pointer.)
+template <typename Tile>
+__device__ __forceinline__ void tile_row_quad(Tile& tile, int trow, int pair, u32 (&d)[4]) {
+    const int off0 = trow * kTileStride + 8 * pair;
+    int off1 = off0 + 8;
+    asm volatile("" : "+v"(off1));
+    const uint2 a = *reinterpret_cast<const uint2*>(&tile[off0]), b = *reinterpret_cast<const uint2*>(&tile[off1]);
+    d[0] = a.x;
+    d[1] = a.y;
+    d[2] = b.x;
+    d[3] = b.y;
+}
+
+// The exact score of a pixel on one side.  Dark side: v - min over the 16 arcs of 9 ring pixels of the
+// arc maximum = the largest t + 1 at which every pixel of some arc is darker than v - t.  Bright side:
+// max over the arcs of the arc minimum - v (the dark score of the inverted image).  Two separate
+// functions: with the side as a run-time argument the compiler evaluates both sides for every pixel.
+__device__ __forceinline__ void load_ring(const uint8_t* c, int (&x)[16]) {
     constexpr int S = kTileStride;
-    int x[16];
     x[0] = c[3 * S]; x[1] = c[3 * S + 1]; x[2] = c[2 * S + 2]; x[3] = c[S + 3];
     x[4] = c[3]; x[5] = c[-S + 3]; x[6] = c[-2 * S + 2]; x[7] = c[-3 * S + 1];
     x[8] = c[-3 * S]; x[9] = c[-3 * S - 1]; x[10] = c[-2 * S - 2]; x[11] = c[-S - 3];
     x[12] = c[-3]; x[13] = c[S - 3]; x[14] = c[2 * S - 2]; x[15] = c[3 * S - 1];
-    const int v = c[0] ^ inv;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        x[k] ^= inv;
-    }
-    int mx3[16];
+}
+__device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
+
+__device__ __forceinline__ int fast_dark_score(const uint8_t* c) {
+    int x[16], mx3[16];
+    load_ring(c, x);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         mx3[k] = max3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
@@ -492,80 +506,99 @@ __device__ __forceinline__ int fast_side_score(const uint8_t* c, int inv) {
     for (int k = 0; k < 16; ++k) {
         lo = min(lo, max3i(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]));
     }
-    return v - lo;
+    return (int)c[0] - lo;
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32* __restrict__ slots, u32* __restrict__ cell_counts, int n_frames) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
-    __shared__ uint8_t score[66 * 68];
-    __shared__ unsigned short work[4096]; // survivors of the rejection test, one entry per pixel
-    __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
-    __shared__ int rowbase[65];
-    __shared__ int nwork;
-    __shared__ int ncorner;
-    __shared__ int total;
-    constexpr int kWorkHalf = 2048;
-    bool compact = false;
+__device__ __forceinline__ int fast_bright_score(const uint8_t* c) {
+    int x[16], mn3[16];
+    load_ring(c, x);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn3[k] = min3i(x[k], x[(k + 1) & 15], x[(k + 2) & 15]);
+    }
+    int hi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        hi = max(hi, min3i(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]));
+    }
+    return hi - (int)c[0];
+}
 
-    const int blk = xcd_contiguous_block(p.total_cells * n_frames);
-    if (blk < 0) {
-        return;
-    }
-    const int frame = blk / p.total_cells;
-    int cell = blk - frame * p.total_cells;
-    int level = 0;
-#pragma unroll 1
-    for (int l = 1; l < p.num_levels; ++l) {
-        if (cell >= p.lv[l].cell_base) {
-            level = l;
-        }
-    }
+// Workgroup barrier that orders LDS accesses only: no wait for outstanding global loads and stores
+// (the cell kernel only exchanges data through LDS; its global stores are final outputs).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// What one cell needs to know about itself (the same in every thread of the workgroup).
+struct fast_item {
+    int ci, cj;          // cell row / column inside its level
+    int min_x, min_y;    // window origin inside the level image
+    int th;              // window rows
+    int iw, ih;          // interior (scanned) columns / rows
+    int skip;            // the reference skips the cell, or nothing is left to scan
+    int dwords_inside;   // every tile dword lies inside its image row
+    int gw;              // level width
+    float scale;         // scale_factors_[level]
+    long long out_cell;  // frame * total_cells + flattened cell
+    const uint8_t* img;  // level image of the frame
+    long long pitch;
+};
+
+// cell_tab[c] = level | cell row << 8 | cell column << 20 for the flattened cell c of a frame
+__device__ __forceinline__ void fast_geometry(const plan_dev& p, const image_src& s, const u32* __restrict__ cell_tab, int item, fast_item& it) {
+    const int frame = item / p.total_cells;
+    const int cell = item - frame * p.total_cells;
+    const u32 t = (u32)__builtin_amdgcn_readfirstlane((int)cell_tab[cell]);
+    const int level = (int)(t & 0xFFu);
+    it.ci = (int)((t >> 8) & 0xFFFu);
+    it.cj = (int)(t >> 20);
     const level_geom& g = p.lv[level];
-    cell -= g.cell_base;
-    const int ci = cell / g.cells_x, cj = cell - ci * g.cells_x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long out_cell = (long long)frame * p.total_cells + g.cell_base + cell;
-
+    it.out_cell = (long long)frame * p.total_cells + cell;
+    it.gw = g.w;
+    it.scale = g.scale;
     const int max_border_x = g.w - kBorder, max_border_y = g.h - kBorder;
-    const int min_x = kBorder + cj * kCell, min_y = kBorder + ci * kCell;
+    it.min_x = kBorder + it.cj * kCell;
+    it.min_y = kBorder + it.ci * kCell;
     // cells the reference skips (orb_extractor.cc:310,323)
-    bool skip = (max_border_y - kOverlap <= min_y) || (max_border_x - kOverlap <= min_x);
-    const int max_x = min(min_x + kCell + kOverlap, max_border_x);
-    const int max_y = min(min_y + kCell + kOverlap, max_border_y);
+    bool skip = (max_border_y - kOverlap <= it.min_y) || (max_border_x - kOverlap <= it.min_x);
+    const int max_x = min(it.min_x + kCell + kOverlap, max_border_x);
+    const int max_y = min(it.min_y + kCell + kOverlap, max_border_y);
     if (!skip && s.mask) {
         // orb_extractor.cc:332-337
-        skip = mask_is_zero(s, min_y, min_x, g.scale) || mask_is_zero(s, max_y, min_x, g.scale)
-               || mask_is_zero(s, min_y, max_x, g.scale) || mask_is_zero(s, max_y, max_x, g.scale);
+        skip = mask_is_zero(s, it.min_y, it.min_x, g.scale) || mask_is_zero(s, max_y, it.min_x, g.scale)
+               || mask_is_zero(s, it.min_y, max_x, g.scale) || mask_is_zero(s, max_y, max_x, g.scale);
     }
-    const int tw = max_x - min_x, th = max_y - min_y;
-    const int iw = tw - 6, ih = th - 6;
-    if (skip || iw <= 0 || ih <= 0) {
-        if (tid == 0) {
-            cell_counts[out_cell] = 0;
-        }
-        return;
-    }
+    it.th = max_y - it.min_y;
+    it.iw = max_x - it.min_x - 6;
+    it.ih = it.th - 6;
+    it.skip = (skip || it.iw <= 0 || it.ih <= 0) ? 1 : 0;
+    it.img = level_ptr(p, s, frame, level, it.pitch);
+    it.dwords_inside = it.min_x + 71 <= g.w ? 1 : 0;
+}
 
-    // tile rows as 18 dwords starting one pixel left of the window, so that interior column c sits
-    // at byte c + 4 of its row (strips of four interior pixels are dword aligned in LDS)
-    long long pitch;
-    const uint8_t* img = level_ptr(p, s, frame, level, pitch);
-    if (min_x + 71 <= g.w) {
+// Tile rows are 18 dwords starting one pixel left of the window, so that interior column c sits at
+// byte c + 4 of its row (strips of four interior pixels are dword aligned in LDS).
+template <typename Tile>
+__device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int lane, int wave, Tile& tile) {
+    if (it.dwords_inside) {
         // every tile dword lies inside its image row: a wave fetches three rows at a time (18
         // lanes per row), all six fetches of a lane in flight before the first LDS write.  Each
         // fetch is the aligned dword pair around the address.
         const int lr = (lane * 57) >> 10; // lane / 18 for lane < 64
         const int kk = lane - 18 * lr;
         const int r0 = wave * 3 + lr;
-        const uint8_t* base = img + (long long)min_y * pitch + (min_x - 1);
+        const uint8_t* base = it.img + (long long)it.min_y * it.pitch + (it.min_x - 1);
         const u32 mis = (u32)(reinterpret_cast<uintptr_t>(base) & 3);
         const uint8_t* base_al = base - mis;
-        const u32 row_step = 12u * (u32)pitch;
-        u32 off = (u32)r0 * (u32)pitch + 4u * (u32)kk + mis;
+        const u32 row_step = 12u * (u32)it.pitch;
+        u32 off = (u32)r0 * (u32)it.pitch + 4u * (u32)kk + mis;
         u32 lo[6], hi[6], sh[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const bool on = lr < 3 && r0 + 12 * j < th;
+            const bool on = lr < 3 && r0 + 12 * j < it.th;
             sh[j] = off & 3u;
             const u32* q = reinterpret_cast<const u32*>(base_al + (off & ~3u));
             lo[j] = on ? q[0] : 0u;
@@ -574,215 +607,291 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, u32
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            if (lr < 3 && r0 + 12 * j < th) {
-                reinterpret_cast<u32*>(tile)[(r0 + 12 * j) * 18 + kk] = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh[j]);
+            if (lr < 3 && r0 + 12 * j < it.th) {
+                reinterpret_cast<u32*>(&tile[0])[(r0 + 12 * j) * 18 + kk] = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh[j]);
             }
         }
     }
     else {
-        for (int i = tid; i < th * 18; i += 256) {
+        // a window at the right image border: byte by byte where a dword would cross the row end
+        for (int i = tid; i < it.th * 18; i += 256) {
             const int r = i / 18, k = i - r * 18;
-            const int x = min_x - 1 + 4 * k;
-            const uint8_t* src = img + (long long)(min_y + r) * pitch;
+            const int x = it.min_x - 1 + 4 * k;
+            const uint8_t* src = it.img + (long long)(it.min_y + r) * it.pitch;
             u32 v;
-            if (x + 3 < g.w) {
+            if (x + 3 < it.gw) {
                 v = load_u32_unaligned(src + x);
             }
             else {
                 v = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    if (x + b < g.w) {
+                    if (x + b < it.gw) {
                         v |= (u32)src[x + b] << (8 * b);
                     }
                 }
             }
-            reinterpret_cast<u32*>(tile)[r * 18 + k] = v;
+            reinterpret_cast<u32*>(&tile[0])[r * 18 + k] = v;
         }
     }
-    for (int i = tid; i < 66 * 68 / 4; i += 256) {
-        reinterpret_cast<u32*>(score)[i] = 0;
-    }
-    __syncthreads();
+}
 
-    int thr = min(max(p.ini_thr, 0), 255);
-    const int min_thr = min(max(p.min_thr, 0), 255);
-    // stage A geometry of this thread: strip of four columns, rows r_first + 16 k; two mask bits
-    // per pixel, set for the pixels inside the interior
-    const int strip = tid & 15, r_first = tid >> 4;
-    u32 valid_bits = 0xFFFFFFFFu;
-    if (iw < 64 || ih < 64) { // a window cut by the image border (same decision in every thread)
-        valid_bits = 0;
-        const u32 cols = (1u << (2 * min(max(iw - 4 * strip, 0), 4))) - 1u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (r_first + 16 * k < ih) {
-                valid_bits |= cols << (8 * k);
-            }
-        }
+__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, const u32* __restrict__ cell_tab, u32* __restrict__ slots,
+                                                    u32* __restrict__ cell_counts, int n_frames) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
+    __shared__ __attribute__((aligned(16))) uint8_t score[66 * 68 + 8];
+    // survivors of the rejection test, one entry per pixel: those that passed the dark test (or both)
+    // from the front, those that passed the bright test only from the back
+    __shared__ unsigned short work[4096];
+    __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
+    __shared__ int rowbase[65];
+    __shared__ u32 nwork; // dark-side items | bright-side items << 16
+    __shared__ int ncorner;
+    __shared__ int total;
+    constexpr int kCompactMax = 1365; // 3 * kCompactMax < 4096: dark, corner and kept lists fit side by side
+    bool compact = false;
+
+    const int item = xcd_contiguous_block(p.total_cells * n_frames);
+    if (item < 0) {
+        return;
     }
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    fast_item cur;
+    fast_geometry(p, s, cell_tab, item, cur);
+    if (cur.skip) {
         if (tid == 0) {
-            nwork = 0;
-            ncorner = 0;
-            total = 0;
-        }
-        if (tid < 128) {
-            keep32[tid] = 0;
-        }
-        __syncthreads();
-        // stage A: rejection test, 16 strips x 64 rows, four strip-rows per thread (rows r, r + 16,
-        // r + 32, r + 48).  Bit 2 * (4 * k + j) of `m` = pixel j of strip-row k passed the dark
-        // test, the next bit = it passed the bright test (one v_dot4 per side turns four flag
-        // bytes into mask bits).  Survivors are appended to the work list: a wave prefix sum over
-        // the per-lane counts, one LDS atomic per wave, then every lane writes its own items.  An
-        // item is row << 6 | column, bit 12 = passed the dark test, bit 13 = the bright test.
-        {
-            const pk16 cpk = {(unsigned short)(255 - thr), (unsigned short)(255 - thr)};
-            u32 acc[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                u32 xd, xb;
-                fast_quick_flags(tile, r_first + 16 * k + 3, strip, cpk, xd, xb);
-                acc[k] = __builtin_amdgcn_udot4(xb, 0x80200802u, __builtin_amdgcn_udot4(xd, 0x40100401u, 0u, false), false);
-            }
-            const u32 m = (acc[0] | (acc[1] << 8) | (acc[2] << 16) | (acc[3] << 24)) & valid_bits;
-            u32 px = (m | (m >> 1)) & 0x55555555u;
-            const int cnt = __popc(px);
-            const int incl = wave_incl_scan(cnt);
-            const int wave_total = __builtin_amdgcn_readlane(incl, 63);
-            if (wave_total) {
-                int base = 0;
-                if (lane == 0) {
-                    base = atomicAdd(&nwork, wave_total);
-                }
-                int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
-                const u32 item0 = ((u32)r_first << 6) | (4u * (u32)strip);
-                while (px) {
-                    const u32 b = (u32)__builtin_ctz(px); // 2 * (4 * k + j)
-                    px &= px - 1u;
-                    // k << 10 (row + 16 k) | j | side flags << 12
-                    work[pos++] = (unsigned short)(item0 + ((b & 0x18u) << 7) + ((b >> 1) & 3u) + (((m >> b) & 3u) << 12));
-                }
-            }
-        }
-        __syncthreads();
-        // stage B: exact score of the survivors from the side that passed (a pixel that passed the
-        // test on one side only cannot reach the threshold on the other, so the side score
-        // decides; both sides for the rare pixel that passed both); below the threshold: 0.
-        // Items that reach the threshold go to a second list in the upper half of `work` (when
-        // the first list leaves it free), the suppression pass then only walks those.
-        const int nw = nwork;
-        compact = nw <= kWorkHalf;
-        for (int i = tid; i < nw; i += 256) {
-            const u32 item = work[i];
-            const int r = (item >> 6) & 63, c = item & 63;
-            const uint8_t* centre = &tile[(r + 3) * kTileStride + c + 4];
-            int sc = fast_side_score(centre, (item & 0x1000u) ? 0 : 0xFF) - 1;
-            if ((item & 0x3000u) == 0x3000u) {
-                sc = max(sc, fast_side_score(centre, 0xFF) - 1);
-            }
-            const bool corner = sc >= thr;
-            score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
-            if (compact && corner) {
-                work[kWorkHalf + atomicAdd(&ncorner, 1)] = (unsigned short)item;
-            }
-        }
-        __syncthreads();
-        // non-maximum suppression (every pixel that is not on the list scores 0); in compact mode
-        // the kept items are collected at the start of `work`, which nobody reads any more
-        const unsigned short* nms_list = compact ? work + kWorkHalf : work;
-        const int nms_n = compact ? ncorner : nw;
-        for (int i = tid; i < nms_n; i += 256) {
-            const u32 item = nms_list[i];
-            const int r = (item >> 6) & 63, c = item & 63;
-            const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
-            const int sc = sp[0];
-            if (sc >= thr) {
-                int m = 0;
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (dy != 0 || dx != 0) {
-                            m = max(m, (int)sp[dy * 68 + dx]);
-                        }
-                    }
-                }
-                if (sc > m) {
-                    atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
-                    const int k = atomicAdd(&total, 1);
-                    if (compact) {
-                        work[k] = (unsigned short)item;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (total != 0 || pass == 1 || min_thr == thr) {
-            break;
-        }
-        thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
-        __syncthreads();
-    }
-    if (total == 0) {
-        if (tid == 0) {
-            cell_counts[out_cell] = 0;
+            cell_counts[cur.out_cell] = 0;
         }
         return;
     }
+    fast_load_tile(cur, tid, lane, wave, tile);
+    // the score plane starts at zero: 4496 bytes as 281 16-byte stores
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(score)[tid] = z;
+        if (tid < 25) {
+            reinterpret_cast<uint4*>(score)[256 + tid] = z;
+        }
+    }
+    lds_barrier();
 
-    const int n_items = compact ? total : nwork; // the kept items, or every survivor of the rejection test
-    if (s.mask) {
-        // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
-        for (int i = tid; i < n_items; i += 256) {
-            const u32 item = work[i];
-            const int r = (item >> 6) & 63, c = item & 63;
-            if ((keep32[2 * r + (c >> 5)] >> (c & 31)) & 1u) {
-                const unsigned y = kBorder + ci * kCell + 3 + r;
-                const unsigned x = kBorder + cj * kCell + 3 + c;
-                if (mask_is_zero(s, y, x, g.scale)) {
-                    atomicAnd(&keep32[2 * r + (c >> 5)], ~(1u << (c & 31)));
+int thr = min(max(p.ini_thr, 0), 255);
+const int min_thr = min(max(p.min_thr, 0), 255);
+// stage A geometry of this thread: eight columns (two strips of four, `pair`) of the rows r_first and
+// r_first + 32; two mask bits per pixel, set for the pixels inside the interior.  The 32 lanes of a
+// half wave cover eight pairs of the rows r, r + 8, r + 16, r + 24: with 18 dwords per tile row
+// those rows start 16 banks apart (18 * 8 = 144 = 2 * 64 + 16), so the 8-byte reads of a half wave
+// fall on 64 different banks.
+const int pair = lane & 7, r_first = 2 * wave + (lane >> 5) + 8 * ((lane >> 3) & 3);
+u32 valid_bits = 0xFFFFFFFFu;
+if (cur.iw < 64 || cur.ih < 64) { // a window cut by the image border (same decision in every thread)
+    valid_bits = 0;
+    const u32 cols = (u32)((1ull << (2 * min(max(cur.iw - 8 * pair, 0), 8))) - 1ull);
+    #pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (r_first + 32 * k < cur.ih) {
+            valid_bits |= cols << (16 * k);
+        }
+    }
+}
+    #pragma unroll 1
+for (int pass = 0; pass < 2; ++pass) {
+    if (tid == 0) {
+        nwork = 0;
+        ncorner = 0;
+        total = 0;
+    }
+    if (tid < 128) {
+        keep32[tid] = 0;
+    }
+    lds_barrier();
+    // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 2 * (8 * k + j)
+    // of `m` = pixel j (0..7) of row k passed the dark test, the next bit = it passed the bright
+    // test (one v_dot4 per side and strip turns four flag bytes into mask bits).  Survivors are
+    // appended to the work list: a wave prefix sum over the per-lane counts, one LDS atomic per
+    // wave, then every lane writes its own items.  An item is row << 6 | column, bit 12 = passed
+    // the dark test, bit 13 = the bright test.
+    {
+        const pk16 cpk = {(unsigned short)(255 - thr), (unsigned short)(255 - thr)};
+        u32 acc[2];
+    #pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int trow = r_first + 32 * k + 3;
+            u32 c[4], mm[4], pp[4], u3[4], d3[4];
+            tile_row_quad(tile, trow, pair, c);
+            tile_row_quad(tile, trow - 2, pair, mm);
+            tile_row_quad(tile, trow + 2, pair, pp);
+            tile_row_quad(tile, trow - 3, pair, u3);
+            tile_row_quad(tile, trow + 3, pair, d3);
+            u32 xd0, xb0, xd1, xb1;
+            fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], cpk, xd0, xb0);
+            fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], cpk, xd1, xb1);
+            const u32 a0 = __builtin_amdgcn_udot4(xb0, 0x80200802u, __builtin_amdgcn_udot4(xd0, 0x40100401u, 0u, false), false);
+            const u32 a1 = __builtin_amdgcn_udot4(xb1, 0x80200802u, __builtin_amdgcn_udot4(xd1, 0x40100401u, 0u, false), false);
+            acc[k] = a0 | (a1 << 8);
+        }
+        const u32 m = (acc[0] | (acc[1] << 16)) & valid_bits;
+        const u32 md = m & 0x55555555u;               // passed the dark test (maybe both)
+        const u32 mb = (m >> 1) & ~m & 0x55555555u;   // passed the bright test only
+        u32 px = md | mb;
+        const int cnt = __popc(md) | (__popc(mb) << 16);
+        const int incl = wave_incl_scan(cnt);
+        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+        if (wave_total) {
+            u32 base = 0;
+            if (lane == 0) {
+                base = atomicAdd(&nwork, (u32)wave_total);
+            }
+            const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)base) + (u32)(incl - cnt);
+            u32 pos_d = first & 0xFFFFu, pos_b = 4095u - (first >> 16);
+            const u32 item0 = ((u32)r_first << 6) | (8u * (u32)pair);
+            while (px) {
+                const u32 b = (u32)__builtin_ctz(px); // 2 * (8 * k + j)
+                px &= px - 1u;
+                const u32 dark = (md >> b) & 1u;
+                // k << 11 (row + 32 k) | j | side flags << 12
+                work[dark ? pos_d : pos_b] = (unsigned short)(item0 + ((b & 0x10u) << 7) + ((b >> 1) & 7u) + (((m >> b) & 3u) << 12));
+                pos_d += dark;
+                pos_b -= dark ^ 1u;
+            }
+        }
+    }
+    lds_barrier();
+    // stage B: exact score of the survivors from the side that passed (a pixel that passed the
+    // test on one side only cannot reach the threshold on the other, so the side score
+    // decides; both sides for the rare pixel that passed both); below the threshold: 0.
+    // Item i < n_dark comes from the front of `work`, the others from its back: the threads of a
+    // wave take consecutive items, so all but one wave run one side's code only.
+    // Items that reach the threshold go to a second list in the unused middle of `work` (when the
+    // lists are short enough for that and for the third list below), the suppression pass then
+    // only walks those.
+    const u32 nwp = nwork;
+    const int n_dark = (int)(nwp & 0xFFFFu), nw = n_dark + (int)(nwp >> 16);
+    compact = nw <= kCompactMax;
+    unsigned short* corners = work + n_dark; // the unused middle of `work`: at least 4096 - nw entries
+    auto item_at = [&](int i) -> u32 { return i < n_dark ? work[i] : work[4095 - (i - n_dark)]; };
+    for (int i = tid; i < nw; i += 256) {
+        const u32 item = item_at(i);
+        const int r = (item >> 6) & 63, c = item & 63;
+        const int toff = (r + 3) * kTileStride + c + 4;
+        int sc;
+        if (i < n_dark) {
+            sc = fast_dark_score(&tile[toff]) - 1;
+            if (item & 0x2000u) {
+                // (the offset passes through an empty asm: otherwise the compiler hoists the bright
+                // score, which both arms contain, in front of the branch and every item pays for it)
+                int toff2 = toff;
+                asm volatile("" : "+v"(toff2));
+                sc = max(sc, fast_bright_score(&tile[toff2]) - 1);
+            }
+        }
+        else {
+            sc = fast_bright_score(&tile[toff]) - 1;
+        }
+        const bool corner = sc >= thr;
+        score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
+        if (compact && corner) {
+            corners[atomicAdd(&ncorner, 1)] = (unsigned short)item;
+        }
+    }
+    lds_barrier();
+    // non-maximum suppression (every pixel that is not on the list scores 0); in compact mode
+    // the kept items are collected from the end of `work` downwards (the bright-side items there
+    // are not read any more; dark + corner + kept items together stay below 4096 entries)
+    const int nms_n = compact ? ncorner : nw;
+    for (int i = tid; i < nms_n; i += 256) {
+        const u32 item = compact ? (u32)corners[i] : item_at(i);
+        const int r = (item >> 6) & 63, c = item & 63;
+        const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
+        const int sc = sp[0];
+        if (sc >= thr) {
+            int m = 0;
+    #pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+    #pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dy != 0 || dx != 0) {
+                        m = max(m, (int)sp[dy * 68 + dx]);
+                    }
+                }
+            }
+            if (sc > m) {
+                atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
+                const int k = atomicAdd(&total, 1);
+                if (compact) {
+                    work[4095 - k] = (unsigned short)item;
                 }
             }
         }
-        __syncthreads();
     }
+    lds_barrier();
+    if (total != 0 || pass == 1 || min_thr == thr) {
+        break;
+    }
+    thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
+    lds_barrier();
+}
+if (total == 0) {
+    if (tid == 0) {
+        cell_counts[cur.out_cell] = 0;
+    }
+    return;
+}
 
-    if (wave == 0) {
-        const int cnt = __popc(keep32[2 * lane]) + __popc(keep32[2 * lane + 1]);
-        int inc = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int t = __shfl_up(inc, d);
-            if (lane >= d) {
-                inc += t;
+// the kept items (end of `work` downwards), or every survivor of the rejection test (both ends of `work`)
+const int n_dark_f = (int)(nwork & 0xFFFFu);
+const int n_items = compact ? total : n_dark_f + (int)(nwork >> 16);
+auto final_item = [&](int i) -> u32 { return compact ? work[4095 - i] : (i < n_dark_f ? work[i] : work[4095 - (i - n_dark_f)]); };
+if (s.mask) {
+    // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
+    for (int i = tid; i < n_items; i += 256) {
+        const u32 item = final_item(i);
+        const int r = (item >> 6) & 63, c = item & 63;
+        if ((keep32[2 * r + (c >> 5)] >> (c & 31)) & 1u) {
+            const unsigned y = kBorder + cur.ci * kCell + 3 + r;
+            const unsigned x = kBorder + cur.cj * kCell + 3 + c;
+            if (mask_is_zero(s, y, x, cur.scale)) {
+                atomicAnd(&keep32[2 * r + (c >> 5)], ~(1u << (c & 31)));
             }
         }
-        rowbase[lane] = inc - cnt;
-        if (lane == 63) {
-            rowbase[64] = inc;
-        }
     }
-    __syncthreads();
+    lds_barrier();
+}
 
-    // raster order: position = keypoints in the rows above + kept pixels to the left in the row
-    u32* out = slots + out_cell * kSlotsPerCell;
-    for (int i = tid; i < n_items; i += 256) {
-        const u32 item = work[i];
-        const int r = (item >> 6) & 63, c = item & 63;
-        const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
-        if ((bits >> c) & 1ull) {
-            const int pos = rowbase[r] + __popcll(bits & ((1ull << c) - 1ull));
-            const u32 x = cj * kCell + 3 + c; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
-            const u32 y = ci * kCell + 3 + r;
-            out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + c + 1] << 24);
+if (wave == 0) {
+    const int cnt = __popc(keep32[2 * lane]) + __popc(keep32[2 * lane + 1]);
+    int inc = cnt;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(inc, d);
+        if (lane >= d) {
+            inc += t;
         }
     }
-    if (tid == 0) {
-        cell_counts[out_cell] = rowbase[64];
+    rowbase[lane] = inc - cnt;
+    if (lane == 63) {
+        rowbase[64] = inc;
     }
+}
+lds_barrier();
+
+// raster order: position = keypoints in the rows above + kept pixels to the left in the row
+u32* out = slots + cur.out_cell * kSlotsPerCell;
+for (int i = tid; i < n_items; i += 256) {
+    const u32 item = final_item(i);
+    const int r = (item >> 6) & 63, c = item & 63;
+    const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
+    if ((bits >> c) & 1ull) {
+        const int pos = rowbase[r] + __popcll(bits & ((1ull << c) - 1ull));
+        const u32 x = cur.cj * kCell + 3 + c; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
+        const u32 y = cur.ci * kCell + 3 + r;
+        out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + c + 1] << 24);
+    }
+}
+if (tid == 0) {
+    cell_counts[cur.out_cell] = rowbase[64];
+}
+
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1908,6 +2017,7 @@ struct ovs_orb {
     int plan_w = 0, plan_h = 0;
     plan_dev plan;
     ovs::dev_buffer tabs;
+    ovs::dev_buffer cell_tab; // per flattened cell of a frame: level | cell row << 8 | cell column << 20
     bool constants_uploaded = false;
 
     // rectangle mask (orb_extractor.cc:82-85: created once, for the size of the first image)
@@ -2149,8 +2259,33 @@ int build_plan(ovs_orb* h, int width, int height) {
     if (quadtree_lds_bytes(p) > 160 * 1024) {
         return ovs::fail(OVS_ERR_UNSUPPORTED, "keypoint quota per level too large for the on-chip quadtree");
     }
-    OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(quadtree_lds_bytes(p))));
+    {
+        // dynamic LDS of the quadtree kernel: granted once per device, to the most a workgroup can
+        // have, and never lowered (plans of other handles and threads share the kernel)
+        static std::mutex mu;
+        static std::set<int> granted;
+        int dev = 0;
+        OVS_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (!granted.count(dev)) {
+            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            granted.insert(dev);
+        }
+    }
+    {
+        std::vector<u32> cell_tab(static_cast<size_t>(p.total_cells));
+        for (int l = 0; l < L; ++l) {
+            const level_geom& g = p.lv[l];
+            for (int c = 0; c < g.cells_x * g.cells_y; ++c) {
+                cell_tab[g.cell_base + c] = static_cast<u32>(l) | (static_cast<u32>(c / g.cells_x) << 8) | (static_cast<u32>(c % g.cells_x) << 20);
+            }
+        }
+        int rc = h->cell_tab.reserve(std::max<size_t>(cell_tab.size() * sizeof(u32), 256));
+        if (rc != OVS_OK) {
+            return rc;
+        }
+        OVS_HIP(hipMemcpy(h->cell_tab.ptr, cell_tab.data(), cell_tab.size() * sizeof(u32), hipMemcpyHostToDevice));
+    }
     if (!tabs.empty()) {
         int rc = h->tabs.reserve(tabs.size() * sizeof(int));
         if (rc != OVS_OK) {
@@ -2284,7 +2419,7 @@ void ovs_orb_destroy(ovs_orb* h) {
         return;
     }
     ovs::device_guard guard(h->device);
-    for (ovs::dev_buffer* b : {&h->tabs, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand,
+    for (ovs::dev_buffer* b : {&h->tabs, &h->cell_tab, &h->rect_mask, &h->pyr, &h->blur, &h->slots, &h->cell_counts, &h->cand,
                                &h->lvl_xy, &h->lvl_resp, &h->lvl_count, &h->st_img, &h->st_mask, &h->st_out}) {
         b->release();
     }
@@ -2471,8 +2606,8 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     if (forked) {
         OVS_HIP(hipEventRecord(h->ev_join, blur_stream));
     }
-    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells * n_frames)), dim3(256), 0, stream,
-               p, src, h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
+    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(static_cast<long long>(p.total_cells) * n_frames)), dim3(256), 0, stream,
+               p, src, h->cell_tab.as<u32>(), h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(n_frames, p.num_levels), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());

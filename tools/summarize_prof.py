@@ -34,7 +34,7 @@ def main():
             w.writerows(rows)
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     meta = {}
-    for p in ("sq1", "sq2", "fetch", "write"):
+    for p in ("sq1", "sq2", "sq3", "fetch", "write"):
         fn = out / p / (p + "_counter_collection.csv")
         if not fn.exists():
             continue
