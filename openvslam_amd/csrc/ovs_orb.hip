@@ -398,22 +398,15 @@ __device__ __forceinline__ bool mask_is_zero(const image_src& s, unsigned y, uns
 
 constexpr int kTileStride = 72; // bytes per LDS tile row; byte b of a row is image column min_x - 1 + b
 
-// Stage A of the FAST kernel for one strip of four horizontally adjacent pixels: the high-speed
-// rejection test on the four opposite ring pairs (0,8) (2,10) (4,12) (6,14).  A pixel that is a
-// corner at threshold t has, in every opposite pair, at least one pixel darker than v - t, or in
-// every pair at least one brighter than v + t (any arc of 9 covers one pixel of each pair):
-//   dark   <=>  max over pairs of min(pair)  <  v - t
-//   bright <=>  min over pairs of max(pair)  >  v + t
-// The four pixels are processed as two registers of two u16 lanes ("even" = columns c, c + 2 and
-// "odd" = c + 1, c + 3): every ring operand is one v_perm_b32 that picks its two bytes out of the
-// tile dwords, the rest is v_pk_min/max_u16 and saturating v_pk_sub_u16.
-typedef unsigned short pk16 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ pk16 pick2(u32 hi, u32 lo, u32 sel) { return __builtin_bit_cast(pk16, __builtin_amdgcn_perm(hi, lo, sel)); }
-__device__ __forceinline__ pk16 pk_min(pk16 a, pk16 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
-__device__ __forceinline__ pk16 pk_sub_sat(pk16 a, pk16 b) { return __builtin_elementwise_sub_sat(a, b); }
-
+// Stage A of the FAST kernel for one strip of four horizontally adjacent pixels: a rejection test on
+// the four opposite ring pairs (0,8) (2,10) (4,12) (6,14).  A pixel that is a corner at threshold t
+// has, in every opposite pair, at least one pixel darker than v - t, or in every pair at least one
+// brighter than v + t (any arc of 9 covers one pixel of each pair).  The test runs on the pixels'
+// upper six bits, four pixels per register, with plain 32-bit integer adds and bit operations
+// (the packed 16-bit min / max / permute instructions issue at about half their rate):
+//   x < v - t  =>  (x >> 2) <= (v >> 2) - T      x > v + t  =>  (x >> 2) >= (v >> 2) + T      T = (t + 1) >> 2
+// so the six-bit test never rejects a corner; it lets a few more pixels through than the exact one
+// would (stage B computes the exact score of whatever passes).
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts.
 __device__ __forceinline__ int wave_incl_scan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
@@ -425,42 +418,21 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-// `cpk` holds 255 - t in both halves.  With D = max over pairs of min(pair), B = min over pairs of
-// max(pair), all values <= 255 in 16-bit lanes:
-//   v - D > t  <=>  sat((v + 255 - t) - D) >= 256      B - v > t  <=>  B + sat((255 - t) - v) >= 256
-// so each flag is bit 8 of a 16-bit lane, i.e. the upper byte of the lane is 0 or 1.  One v_perm
-// collects the four flag bytes of a side in pixel order; the caller turns them into mask bits
-// with one v_dot4 per side.  `xd` / `xb`: byte p = 1 iff pixel c + p passed the dark / bright test.
-// c0, c1, c2 / m0, m1, m2 / p0, p1, p2: the three dwords around the strip (columns c - 4 .. c + 7) of the
-// strip's row and of the rows two above and two below; up3 / dn3: the strip's own dword of the rows
-// three above and below.
-__device__ __forceinline__ void fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0, u32 m1, u32 m2, u32 p0, u32 p1, u32 p2, u32 up3, u32 dn3,
-                                                 pk16 cpk, u32& xd, u32& xb) {
-    // selector bytes 0..3 address the second v_perm source, 4..7 the first, 0x0c = 0
-    constexpr u32 kEven = 0x0c020c00u, kOdd = 0x0c030c01u;       // (b0, b2), (b1, b3) of one dword
-    constexpr u32 kB2nB0 = 0x0c040c02u, kB3nB1 = 0x0c050c03u;     // (lo.b2, hi.b0), (lo.b3, hi.b1)
-    const pk16 ve = pick2(c1, c1, kEven), vo = pick2(c1, c1, kOdd);
-    // ring 0 (0, +3) / ring 8 (0, -3)
-    const pk16 x0e = pick2(dn3, dn3, kEven), x0o = pick2(dn3, dn3, kOdd);
-    const pk16 x8e = pick2(up3, up3, kEven), x8o = pick2(up3, up3, kOdd);
-    // ring 4 (+3, 0): columns (c+3, c+5) / (c+4, c+6);  ring 12 (-3, 0): (c-3, c-1) / (c-2, c)
-    const pk16 x4e = pick2(c2, c1, kB3nB1), x4o = pick2(c2, c2, kEven);
-    const pk16 x12e = pick2(c0, c0, kOdd), x12o = pick2(c1, c0, kB2nB0);
-    // ring 2 (+2, +2): (c+2, c+4) / (c+3, c+5) of row +2;  ring 14 (-2, +2): (c-2, c) / (c-1, c+1)
-    const pk16 x2e = pick2(p2, p1, kB2nB0), x2o = pick2(p2, p1, kB3nB1);
-    const pk16 x14e = pick2(p1, p0, kB2nB0), x14o = pick2(p1, p0, kB3nB1);
-    // ring 6 (+2, -2) and ring 10 (-2, -2): the same columns of row -2
-    const pk16 x6e = pick2(m2, m1, kB2nB0), x6o = pick2(m2, m1, kB3nB1);
-    const pk16 x10e = pick2(m1, m0, kB2nB0), x10o = pick2(m1, m0, kB3nB1);
-    const pk16 de = pk_max(pk_max(pk_min(x0e, x8e), pk_min(x2e, x10e)), pk_max(pk_min(x4e, x12e), pk_min(x6e, x14e)));
-    const pk16 dod = pk_max(pk_max(pk_min(x0o, x8o), pk_min(x2o, x10o)), pk_max(pk_min(x4o, x12o), pk_min(x6o, x14o)));
-    const pk16 be = pk_min(pk_min(pk_max(x0e, x8e), pk_max(x2e, x10e)), pk_min(pk_max(x4e, x12e), pk_max(x6e, x14e)));
-    const pk16 bo = pk_min(pk_min(pk_max(x0o, x8o), pk_max(x2o, x10o)), pk_min(pk_max(x4o, x12o), pk_max(x6o, x14o)));
-    const u32 fde = __builtin_bit_cast(u32, pk_sub_sat(ve + cpk, de)), fdo = __builtin_bit_cast(u32, pk_sub_sat(vo + cpk, dod));
-    const u32 fbe = __builtin_bit_cast(u32, be + pk_sub_sat(cpk, ve)), fbo = __builtin_bit_cast(u32, bo + pk_sub_sat(cpk, vo));
-    constexpr u32 kFlagBytes = 0x07030501u; // (even.b1, odd.b1, even.b3, odd.b3) = pixels c .. c + 3
-    xd = __builtin_amdgcn_perm(fdo, fde, kFlagBytes);
-    xb = __builtin_amdgcn_perm(fbo, fbe, kFlagBytes);
+// `lo`, `mid`, `hi`: three consecutive dwords of the six-bit tile (bytes = columns c - 4 .. c + 7) of the
+// strip's row (c*), of the rows two above (m*) and two below (p*); up3 / dn3: the strip's own dword of the
+// rows three above and below.  `kq` holds 128 - T in every byte.  With six-bit values in eight-bit
+// fields neither v + (128 - T) - x nor (128 - T) - v + x leaves its byte, and bit 7 of the byte says
+// whether x <= v - T, respectively x >= v + T.  Returns bit 2 j = pixel c + j passed the dark test,
+// bit 2 j + 1 = it passed the bright test.
+__device__ __forceinline__ u32 fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0, u32 m1, u32 m2, u32 p0, u32 p1, u32 p2, u32 up3, u32 dn3, u32 kq) {
+    const u32 x4 = __builtin_amdgcn_alignbyte(c2, c1, 3), x12 = __builtin_amdgcn_alignbyte(c1, c0, 1);  // columns + 3 / - 3
+    const u32 x2 = __builtin_amdgcn_alignbyte(p2, p1, 2), x14 = __builtin_amdgcn_alignbyte(p1, p0, 2);  // row + 2, columns + 2 / - 2
+    const u32 x6 = __builtin_amdgcn_alignbyte(m2, m1, 2), x10 = __builtin_amdgcn_alignbyte(m1, m0, 2);  // row - 2
+    const u32 vd = c1 + kq, vb = kq - c1;
+    const u32 dark = ((vd - dn3) | (vd - up3)) & ((vd - x2) | (vd - x10)) & ((vd - x4) | (vd - x12)) & ((vd - x6) | (vd - x14));
+    const u32 bright = ((vb + dn3) | (vb + up3)) & ((vb + x2) | (vb + x10)) & ((vb + x4) | (vb + x12)) & ((vb + x6) | (vb + x14));
+    const u32 w = ((dark >> 7) & 0x01010101u) | ((bright >> 6) & 0x02020202u);
+    return __builtin_amdgcn_udot4(w, 0x40100401u, 0u, false);
 }
 
 // The four dwords 2 * pair .. 2 * pair + 3 of a tile row (columns 8 * pair - 4 .. 8 * pair + 11 of the
@@ -579,36 +551,31 @@ __device__ __forceinline__ void fast_geometry(const plan_dev& p, const image_src
     it.dwords_inside = it.min_x + 71 <= g.w ? 1 : 0;
 }
 
+typedef u32 u32_unaligned __attribute__((aligned(1)));
+
 // Tile rows are 18 dwords starting one pixel left of the window, so that interior column c sits at
 // byte c + 4 of its row (strips of four interior pixels are dword aligned in LDS).
 template <typename Tile>
-__device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int lane, int wave, Tile& tile) {
+__device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int lane, int wave, Tile& tile, Tile& tile6) {
     if (it.dwords_inside) {
         // every tile dword lies inside its image row: a wave fetches three rows at a time (18
-        // lanes per row), all six fetches of a lane in flight before the first LDS write.  Each
-        // fetch is the aligned dword pair around the address.
+        // lanes per row), all six fetches of a lane in flight before the first LDS write.  The
+        // addresses have no particular alignment (the memory pipeline splits a dword that straddles
+        // a cache line); rows past the window read its last row again and are not stored.
         const int lr = (lane * 57) >> 10; // lane / 18 for lane < 64
         const int kk = lane - 18 * lr;
         const int r0 = wave * 3 + lr;
-        const uint8_t* base = it.img + (long long)it.min_y * it.pitch + (it.min_x - 1);
-        const u32 mis = (u32)(reinterpret_cast<uintptr_t>(base) & 3);
-        const uint8_t* base_al = base - mis;
-        const u32 row_step = 12u * (u32)it.pitch;
-        u32 off = (u32)r0 * (u32)it.pitch + 4u * (u32)kk + mis;
-        u32 lo[6], hi[6], sh[6];
+        const uint8_t* base = it.img + (long long)it.min_y * it.pitch + (it.min_x - 1) + 4 * kk;
+        u32 v[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const bool on = lr < 3 && r0 + 12 * j < it.th;
-            sh[j] = off & 3u;
-            const u32* q = reinterpret_cast<const u32*>(base_al + (off & ~3u));
-            lo[j] = on ? q[0] : 0u;
-            hi[j] = (on && sh[j]) ? q[1] : 0u;
-            off += row_step;
+            v[j] = *reinterpret_cast<const u32_unaligned*>(base + (u32)min(r0 + 12 * j, it.th - 1) * (u32)it.pitch);
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            if (lr < 3 && r0 + 12 * j < it.th) {
-                reinterpret_cast<u32*>(&tile[0])[(r0 + 12 * j) * 18 + kk] = __builtin_amdgcn_alignbyte(hi[j], lo[j], sh[j]);
+            if (lr < 3 && r0 + 12 * j < 70) {
+                reinterpret_cast<u32*>(&tile[0])[(r0 + 12 * j) * 18 + kk] = v[j];
+                reinterpret_cast<u32*>(&tile6[0])[(r0 + 12 * j) * 18 + kk] = (v[j] >> 2) & 0x3F3F3F3Fu;
             }
         }
     }
@@ -632,6 +599,7 @@ __device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int
                 }
             }
             reinterpret_cast<u32*>(&tile[0])[r * 18 + k] = v;
+            reinterpret_cast<u32*>(&tile6[0])[r * 18 + k] = (v >> 2) & 0x3F3F3F3Fu;
         }
     }
 }
@@ -639,7 +607,12 @@ __device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int
 __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, const u32* __restrict__ cell_tab, u32* __restrict__ slots,
                                                     u32* __restrict__ cell_counts, int n_frames) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
-    __shared__ __attribute__((aligned(16))) uint8_t score[66 * 68 + 8];
+    // one array, two uses: during the rejection test the tile's pixels >> 2 (same layout as `tile`),
+    // afterwards the score plane (66 rows of 68 bytes)
+    __shared__ __attribute__((aligned(16))) uint8_t plane[70 * kTileStride];
+    static_assert(sizeof(plane) >= 66 * 68 + 8 && sizeof(plane) == 315 * 16, "the score plane fits, whole 16-byte stores clear it");
+    auto& tile6 = plane;
+    auto& score = plane;
     // survivors of the rejection test, one entry per pixel: those that passed the dark test (or both)
     // from the front, those that passed the bright test only from the back
     __shared__ unsigned short work[4096];
@@ -664,15 +637,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
         }
         return;
     }
-    fast_load_tile(cur, tid, lane, wave, tile);
-    // the score plane starts at zero: 4496 bytes as 281 16-byte stores
-    {
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4*>(score)[tid] = z;
-        if (tid < 25) {
-            reinterpret_cast<uint4*>(score)[256 + tid] = z;
-        }
-    }
+    fast_load_tile(cur, tid, lane, wave, tile, tile6);
     lds_barrier();
 
 int thr = min(max(p.ini_thr, 0), 255);
@@ -712,22 +677,19 @@ for (int pass = 0; pass < 2; ++pass) {
     // wave, then every lane writes its own items.  An item is row << 6 | column, bit 12 = passed
     // the dark test, bit 13 = the bright test.
     {
-        const pk16 cpk = {(unsigned short)(255 - thr), (unsigned short)(255 - thr)};
+        const u32 kq = (u32)(128 - ((thr + 1) >> 2)) * 0x01010101u;
         u32 acc[2];
     #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int trow = r_first + 32 * k + 3;
             u32 c[4], mm[4], pp[4], u3[4], d3[4];
-            tile_row_quad(tile, trow, pair, c);
-            tile_row_quad(tile, trow - 2, pair, mm);
-            tile_row_quad(tile, trow + 2, pair, pp);
-            tile_row_quad(tile, trow - 3, pair, u3);
-            tile_row_quad(tile, trow + 3, pair, d3);
-            u32 xd0, xb0, xd1, xb1;
-            fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], cpk, xd0, xb0);
-            fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], cpk, xd1, xb1);
-            const u32 a0 = __builtin_amdgcn_udot4(xb0, 0x80200802u, __builtin_amdgcn_udot4(xd0, 0x40100401u, 0u, false), false);
-            const u32 a1 = __builtin_amdgcn_udot4(xb1, 0x80200802u, __builtin_amdgcn_udot4(xd1, 0x40100401u, 0u, false), false);
+            tile_row_quad(tile6, trow, pair, c);
+            tile_row_quad(tile6, trow - 2, pair, mm);
+            tile_row_quad(tile6, trow + 2, pair, pp);
+            tile_row_quad(tile6, trow - 3, pair, u3);
+            tile_row_quad(tile6, trow + 3, pair, d3);
+            const u32 a0 = fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq);
+            const u32 a1 = fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq);
             acc[k] = a0 | (a1 << 8);
         }
         const u32 m = (acc[0] | (acc[1] << 16)) & valid_bits;
@@ -754,6 +716,15 @@ for (int pass = 0; pass < 2; ++pass) {
                 pos_d += dark;
                 pos_b -= dark ^ 1u;
             }
+        }
+    }
+    lds_barrier();
+    // the rejection test is done with the six-bit tile: its memory becomes the score plane, all zero
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(score)[tid] = z;
+        if (tid < 315 - 256) {
+            reinterpret_cast<uint4*>(score)[256 + tid] = z;
         }
     }
     lds_barrier();
@@ -829,6 +800,9 @@ for (int pass = 0; pass < 2; ++pass) {
         break;
     }
     thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
+    for (int i = tid; i < 70 * 18; i += 256) {
+        reinterpret_cast<u32*>(&tile6[0])[i] = (reinterpret_cast<const u32*>(&tile[0])[i] >> 2) & 0x3F3F3F3Fu;
+    }
     lds_barrier();
 }
 if (total == 0) {
