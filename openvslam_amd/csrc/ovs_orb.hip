@@ -519,36 +519,71 @@ struct fast_item {
     long long pitch;
 };
 
-// cell_tab[c] = level | cell row << 8 | cell column << 20 for the flattened cell c of a frame
-__device__ __forceinline__ void fast_geometry(const plan_dev& p, const image_src& s, const u32* __restrict__ cell_tab, int item, fast_item& it) {
-    const int frame = item / p.total_cells;
-    const int cell = item - frame * p.total_cells;
-    const u32 t = (u32)__builtin_amdgcn_readfirstlane((int)cell_tab[cell]);
-    const int level = (int)(t & 0xFFu);
-    it.ci = (int)((t >> 8) & 0xFFFu);
-    it.cj = (int)(t >> 20);
-    const level_geom& g = p.lv[level];
-    it.out_cell = (long long)frame * p.total_cells + cell;
-    it.gw = g.w;
-    it.scale = g.scale;
+// One record per flattened cell of a frame, built on the host with the plan: everything about the cell
+// that does not depend on the frame or on the mask, so that a workgroup gets its geometry from a
+// single 32-byte scalar load.
+struct fast_cell_rec {
+    u32 origin;   // min_x | min_y << 16: window origin inside the level image
+    u32 extent;   // window rows | interior columns << 8 | interior rows << 16 | level << 24
+    u32 where;    // cell row | cell column << 12 | skip << 24 | dwords_inside << 25
+    int gw;       // level width
+    float scale;  // scale_factors_[level]
+    int pitch;    // row pitch of the level plane (levels >= 1)
+    long long pyr_off; // byte offset of the level inside one frame's pyramid block (levels >= 1)
+};
+static_assert(sizeof(fast_cell_rec) == 32, "one s_load_dwordx8");
+
+fast_cell_rec make_fast_cell_rec(const level_geom& g, int level, int ci, int cj) {
+    fast_cell_rec r{};
     const int max_border_x = g.w - kBorder, max_border_y = g.h - kBorder;
-    it.min_x = kBorder + it.cj * kCell;
-    it.min_y = kBorder + it.ci * kCell;
+    const int min_x = kBorder + cj * kCell, min_y = kBorder + ci * kCell;
     // cells the reference skips (orb_extractor.cc:310,323)
-    bool skip = (max_border_y - kOverlap <= it.min_y) || (max_border_x - kOverlap <= it.min_x);
-    const int max_x = min(it.min_x + kCell + kOverlap, max_border_x);
-    const int max_y = min(it.min_y + kCell + kOverlap, max_border_y);
+    bool skip = (max_border_y - kOverlap <= min_y) || (max_border_x - kOverlap <= min_x);
+    const int max_x = std::min(min_x + kCell + kOverlap, max_border_x);
+    const int max_y = std::min(min_y + kCell + kOverlap, max_border_y);
+    const int th = max_y - min_y, iw = max_x - min_x - 6, ih = th - 6;
+    skip = skip || iw <= 0 || ih <= 0;
+    r.origin = static_cast<u32>(min_x) | (static_cast<u32>(min_y) << 16);
+    r.extent = skip ? 0u : (static_cast<u32>(th) | (static_cast<u32>(iw) << 8) | (static_cast<u32>(ih) << 16));
+    r.extent |= static_cast<u32>(level) << 24;
+    r.where = static_cast<u32>(ci) | (static_cast<u32>(cj) << 12) | (skip ? 1u << 24 : 0u) | (min_x + 71 <= g.w ? 1u << 25 : 0u);
+    r.gw = g.w;
+    r.scale = g.scale;
+    r.pitch = g.pitch;
+    r.pyr_off = g.pyr_off;
+    return r;
+}
+
+__device__ __forceinline__ void fast_geometry(const plan_dev& p, const image_src& s, const fast_cell_rec* __restrict__ cell_tab, int frame, int cell,
+                                              fast_item& it) {
+    const fast_cell_rec rec = cell_tab[cell];
+    it.ci = (int)(rec.where & 0xFFFu);
+    it.cj = (int)((rec.where >> 12) & 0xFFFu);
+    it.out_cell = (long long)frame * p.total_cells + cell;
+    it.gw = rec.gw;
+    it.scale = rec.scale;
+    it.min_x = (int)(rec.origin & 0xFFFFu);
+    it.min_y = (int)(rec.origin >> 16);
+    it.th = (int)(rec.extent & 0xFFu);
+    it.iw = (int)((rec.extent >> 8) & 0xFFu);
+    it.ih = (int)((rec.extent >> 16) & 0xFFu);
+    bool skip = ((rec.where >> 24) & 1u) != 0;
     if (!skip && s.mask) {
         // orb_extractor.cc:332-337
-        skip = mask_is_zero(s, it.min_y, it.min_x, g.scale) || mask_is_zero(s, max_y, it.min_x, g.scale)
-               || mask_is_zero(s, it.min_y, max_x, g.scale) || mask_is_zero(s, max_y, max_x, g.scale);
+        const int max_x = it.min_x + it.iw + 6, max_y = it.min_y + it.th;
+        skip = mask_is_zero(s, it.min_y, it.min_x, rec.scale) || mask_is_zero(s, max_y, it.min_x, rec.scale)
+               || mask_is_zero(s, it.min_y, max_x, rec.scale) || mask_is_zero(s, max_y, max_x, rec.scale);
     }
-    it.th = max_y - it.min_y;
-    it.iw = max_x - it.min_x - 6;
-    it.ih = it.th - 6;
-    it.skip = (skip || it.iw <= 0 || it.ih <= 0) ? 1 : 0;
-    it.img = level_ptr(p, s, frame, level, it.pitch);
-    it.dwords_inside = it.min_x + 71 <= g.w ? 1 : 0;
+    it.skip = skip ? 1 : 0;
+    it.dwords_inside = (int)((rec.where >> 25) & 1u);
+    if ((rec.extent >> 24) == 0) {
+        it.pitch = s.row_stride0;
+        it.img = s.img0 + frame * s.frame_stride0;
+    }
+    else {
+        it.pitch = rec.pitch;
+        it.img = s.pyr + frame * p.frame_pyr_bytes + rec.pyr_off;
+    }
 }
 
 typedef u32 u32_unaligned __attribute__((aligned(1)));
@@ -604,8 +639,12 @@ __device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int
     }
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, const u32* __restrict__ cell_tab, u32* __restrict__ slots,
-                                                    u32* __restrict__ cell_counts, int n_frames) {
+// Grid: x = the cells of a frame (rounded up to a multiple of 8 workgroups), y = frames starting at
+// frame0.  Workgroup x runs on XCD x % 8; the cells of a frame are cut into eight contiguous runs
+// (neighbouring cells share image rows and meet in the XCD's L2) and the run an XCD gets rotates with
+// the frame, because the runs differ in cost (the last one holds the small pyramid levels).
+__global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, const fast_cell_rec* __restrict__ cell_tab, u32* __restrict__ slots,
+                                                    u32* __restrict__ cell_counts, int frame0) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[70 * kTileStride];
     // one array, two uses: during the rejection test the tile's pixels >> 2 (same layout as `tile`),
     // afterwards the score plane (66 rows of 68 bytes)
@@ -616,7 +655,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
     // survivors of the rejection test, one entry per pixel: those that passed the dark test (or both)
     // from the front, those that passed the bright test only from the back
     __shared__ unsigned short work[4096];
-    __shared__ u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
+    __shared__ __attribute__((aligned(8))) u32 keep32[128]; // 64 rows x 64 columns, two dwords per row
     __shared__ int rowbase[65];
     __shared__ u32 nwork; // dark-side items | bright-side items << 16
     __shared__ int ncorner;
@@ -624,13 +663,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
     constexpr int kCompactMax = 1365; // 3 * kCompactMax < 4096: dark, corner and kept lists fit side by side
     bool compact = false;
 
-    const int item = xcd_contiguous_block(p.total_cells * n_frames);
-    if (item < 0) {
+    const int per_run = (p.total_cells + 7) >> 3;
+    const int cell = (int)((blockIdx.x + blockIdx.y) & 7u) * per_run + (int)(blockIdx.x >> 3);
+    if (cell >= p.total_cells || (int)(blockIdx.x >> 3) >= per_run) {
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     fast_item cur;
-    fast_geometry(p, s, cell_tab, item, cur);
+    fast_geometry(p, s, cell_tab, frame0 + (int)blockIdx.y, cell, cur);
     if (cur.skip) {
         if (tid == 0) {
             cell_counts[cur.out_cell] = 0;
@@ -833,15 +873,9 @@ if (s.mask) {
 }
 
 if (wave == 0) {
-    const int cnt = __popc(keep32[2 * lane]) + __popc(keep32[2 * lane + 1]);
-    int inc = cnt;
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(inc, d);
-        if (lane >= d) {
-            inc += t;
-        }
-    }
+    const uint2 kr = reinterpret_cast<const uint2*>(keep32)[lane];
+    const int cnt = __popc(kr.x) + __popc(kr.y);
+    const int inc = wave_incl_scan(cnt);
     rowbase[lane] = inc - cnt;
     if (lane == 63) {
         rowbase[64] = inc;
@@ -1991,7 +2025,7 @@ struct ovs_orb {
     int plan_w = 0, plan_h = 0;
     plan_dev plan;
     ovs::dev_buffer tabs;
-    ovs::dev_buffer cell_tab; // per flattened cell of a frame: level | cell row << 8 | cell column << 20
+    ovs::dev_buffer cell_tab; // fast_cell_rec per flattened cell of a frame
     bool constants_uploaded = false;
 
     // rectangle mask (orb_extractor.cc:82-85: created once, for the size of the first image)
@@ -2247,18 +2281,18 @@ int build_plan(ovs_orb* h, int width, int height) {
         }
     }
     {
-        std::vector<u32> cell_tab(static_cast<size_t>(p.total_cells));
+        std::vector<fast_cell_rec> cell_tab(static_cast<size_t>(p.total_cells));
         for (int l = 0; l < L; ++l) {
             const level_geom& g = p.lv[l];
             for (int c = 0; c < g.cells_x * g.cells_y; ++c) {
-                cell_tab[g.cell_base + c] = static_cast<u32>(l) | (static_cast<u32>(c / g.cells_x) << 8) | (static_cast<u32>(c % g.cells_x) << 20);
+                cell_tab[g.cell_base + c] = make_fast_cell_rec(g, l, c / g.cells_x, c % g.cells_x);
             }
         }
-        int rc = h->cell_tab.reserve(std::max<size_t>(cell_tab.size() * sizeof(u32), 256));
+        int rc = h->cell_tab.reserve(std::max<size_t>(cell_tab.size() * sizeof(fast_cell_rec), 256));
         if (rc != OVS_OK) {
             return rc;
         }
-        OVS_HIP(hipMemcpy(h->cell_tab.ptr, cell_tab.data(), cell_tab.size() * sizeof(u32), hipMemcpyHostToDevice));
+        OVS_HIP(hipMemcpy(h->cell_tab.ptr, cell_tab.data(), cell_tab.size() * sizeof(fast_cell_rec), hipMemcpyHostToDevice));
     }
     if (!tabs.empty()) {
         int rc = h->tabs.reserve(tabs.size() * sizeof(int));
@@ -2580,8 +2614,10 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     if (forked) {
         OVS_HIP(hipEventRecord(h->ev_join, blur_stream));
     }
-    OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(static_cast<long long>(p.total_cells) * n_frames)), dim3(256), 0, stream,
-               p, src, h->cell_tab.as<u32>(), h->slots.as<u32>(), h->cell_counts.as<u32>(), n_frames);
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) { // the y extent of a grid is limited to 65535
+        OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells), std::min(n_frames - f0, 65535)), dim3(256), 0, stream,
+                   p, src, h->cell_tab.as<fast_cell_rec>(), h->slots.as<u32>(), h->cell_counts.as<u32>(), f0);
+    }
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(n_frames, p.num_levels), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
                p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
