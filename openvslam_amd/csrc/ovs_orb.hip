@@ -18,7 +18,7 @@
 //   slots     [frame][cell][1024] u32  FAST survivors of one cell in raster order, packed
 //             x | y << 12 | score << 24 in border-relative level coordinates; 1024 is the exact
 //             maximum 3x3 non-maximum suppression leaves in a 64 x 64 window
-//   cand      [frame][level][cells_l * 1024] dense candidates in the reference's order
+//   cand      [2][frame][level][cells_l * 1024] dense candidates in the reference's order (positions, node ids)
 //             (cells row-major, raster inside a cell): xy and (response << 24 | quadtree node)
 //   lvl_*     [frame][sum ncap_l] per-level keypoints in quadtree list order + [frame][L] counts
 #include "ovs_internal.h"
@@ -1246,7 +1246,9 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
     return (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
 }
 
-// Candidate record: x | y << 16, response << 24 | current node id.
+// Candidate record: x | y << 16 in one array (written once), response << 24 | current node id in a
+// second one (rewritten by every sweep: a wave's 64 records are 256 contiguous bytes, whole cache
+// lines, where an interleaved layout would rewrite half of every line).
 // Every pass over the candidates is latency bound (global loads feeding LDS atomics), and the
 // largest level of a frame is the critical path of the whole launch, so the passes are kept few
 // and deep: moving the candidates to their child nodes and voting into the child counters of the
@@ -1254,14 +1256,14 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
 // before it touches the first result.
 constexpr int kCandDepth = 4; // candidate loads a thread keeps in flight
 template <typename F>
-__device__ __forceinline__ void for_each_candidate(uint2* __restrict__ cand, int N, F&& f) {
+__device__ __forceinline__ void for_each_candidate(const u32* __restrict__ cnode, int N, F&& f) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i0 = tid; i0 < N; i0 += kCandDepth * nt) {
-        uint2 cd[kCandDepth];
+        u32 cd[kCandDepth];
 #pragma unroll
         for (int u = 0; u < kCandDepth; ++u) {
             const int i = i0 + u * nt;
-            cd[u] = cand[min(i, N - 1)];
+            cd[u] = cnode[min(i, N - 1)];
         }
 #pragma unroll
         for (int u = 0; u < kCandDepth; ++u) {
@@ -1282,14 +1284,14 @@ __device__ __forceinline__ void for_each_candidate(uint2* __restrict__ cand, int
 //   stage1(n)                      an extra word read together with the record of node n
 //   stage2(n, rec, b, aux, x, y)   the new node id (may read one more LDS word)
 template <typename Stage1, typename Stage2>
-__device__ __forceinline__ void move_and_vote(uint2* __restrict__ cand, int N, const u32* nc_from, const short4* nb_from,
+__device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* __restrict__ cnode, int N, const u32* nc_from, const short4* nb_from,
                                               const u32* nc_to, const short4* nb_to, u32* votes, Stage1&& stage1, Stage2&& stage2) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i0 = tid; i0 < N; i0 += kCandDepth * nt) {
         uint2 cd[kCandDepth];
 #pragma unroll
         for (int u = 0; u < kCandDepth; ++u) {
-            cd[u] = cand[min(i0 + u * nt, N - 1)];
+            cd[u] = make_uint2(cxy[min(i0 + u * nt, N - 1)], cnode[min(i0 + u * nt, N - 1)]);
         }
         u32 rec[kCandDepth], aux[kCandDepth];
         short4 b[kCandDepth];
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void move_and_vote(uint2* __restrict__ cand, int N, c
         for (int u = 0; u < kCandDepth; ++u) {
             const int i = i0 + u * nt;
             if (i < N) {
-                cand[i].y = (cd[u].y & 0xFF000000u) | nn[u];
+                cnode[i] = (cd[u].y & 0xFF000000u) | nn[u];
                 if (!(rec2[u] & kLeaf)) {
                     atomicAdd(&votes[4 * nn[u] + child_of(b2[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16))], 1u);
                 }
@@ -1326,7 +1328,7 @@ __device__ __forceinline__ void move_and_vote(uint2* __restrict__ cand, int N, c
 }
 
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* __restrict__ slots, const u32* __restrict__ cell_counts,
-                                                         uint2* __restrict__ cand_all,
+                                                         u32* __restrict__ cand_xy_all, u32* __restrict__ cand_node_all,
                                                          u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count) {
     extern __shared__ u32 smem[];
     // Workgroups are dealt round-robin to the 8 XCDs in launch order and a level-0 workgroup runs
@@ -1353,7 +1355,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
 
     const int ncells = g.cells_x * g.cells_y;
     const long long cell0 = (long long)frame * p.total_cells + g.cell_base;
-    uint2* cand = cand_all + frame * p.frame_cand_cap + g.cand_base;
+    u32* cxy = cand_xy_all + frame * p.frame_cand_cap + g.cand_base;
+    u32* cnode = cand_node_all + frame * p.frame_cand_cap + g.cand_base;
     const int quota = g.quota;
 
     for (int c = tid; c < ncells; c += nt) {
@@ -1427,7 +1430,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * nt < N) {
                 const u32 x = v[u] & 0xFFFu, y = (v[u] >> 12) & 0xFFFu, r = v[u] >> 24;
-                cand[idx[u]] = make_uint2(x | (y << 16), (r << 24) | ni[u]);
+                cxy[idx[u]] = x | (y << 16);
+                cnode[idx[u]] = (r << 24) | ni[u];
                 atomicAdd(&t0[ni[u]], 1u);
             }
         }
@@ -1457,7 +1461,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     __syncthreads();
     // compact node ids + votes for the first sweep
     move_and_vote(
-        cand, N, t1, nb_cur, nc_cur, nb_cur, cc, [&](u32) { return 0u; },
+        cxy, cnode, N, t1, nb_cur, nc_cur, nb_cur, cc, [&](u32) { return 0u; },
         [&](u32, u32 compact_id, short4, u32, int, int) { return compact_id; });
     __syncthreads();
 
@@ -1522,7 +1526,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         __syncthreads();
         // move every candidate to its child and vote for the next split of that child
         move_and_vote(
-            cand, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32) { return 0u; },
+            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32) { return 0u; },
             [&](u32 n, u32 rec, short4 b, u32, int x, int y) { return cc[4 * n + ((rec & kLeaf) ? 0 : child_of(b, x, y))]; });
         const int pool = (int)sh[0];
         __syncthreads();
@@ -1644,7 +1648,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         }
         __syncthreads();
         move_and_vote(
-            cand, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32 n) { return t3[n]; },
+            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32 n) { return t3[n]; },
             [&](u32 n, u32 rec, short4 b, u32 kept_before, int x, int y) {
                 const u32 child_id = cc[4 * n + ((rec & kProc) ? child_of(b, x, y) : 0)];
                 return (rec & kProc) ? child_id : (u32)Cn + kept_before;
@@ -1681,15 +1685,15 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         cc[q] = 0;
     }
     __syncthreads();
-    for_each_candidate(cand, N, [&](int i, uint2 cd) {
-        atomicMax(&cc[cd.y & kCnt], (cd.y & 0xFF000000u) | (0xFFFFFFu - (u32)i));
+    for_each_candidate(cnode, N, [&](int i, u32 cd) {
+        atomicMax(&cc[cd & kCnt], (cd & 0xFF000000u) | (0xFFFFFFu - (u32)i));
     });
     __syncthreads();
     const long long ob = (long long)frame * p.kp_total_cap + g.kp_base;
     for (int q = tid; q < S; q += nt) {
         const u32 v = cc[q];
         const u32 i = 0xFFFFFFu - (v & 0xFFFFFFu);
-        lvl_xy[ob + q] = cand[i].x;
+        lvl_xy[ob + q] = cxy[i];
         lvl_resp[ob + q] = (uint8_t)(v >> 24);
     }
     if (tid == 0) {
@@ -2619,7 +2623,7 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
                    p, src, h->cell_tab.as<fast_cell_rec>(), h->slots.as<u32>(), h->cell_counts.as<u32>(), f0);
     }
     OVS_LAUNCH("k_quadtree", k_quadtree, dim3(n_frames, p.num_levels), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
-               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<uint2>(),
+               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<u32>(), h->cand.as<u32>() + static_cast<long long>(n_frames) * p.frame_cand_cap,
                h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
     if (forked) {
         OVS_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
