@@ -422,17 +422,18 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // strip's row (c*), of the rows two above (m*) and two below (p*); up3 / dn3: the strip's own dword of the
 // rows three above and below.  `kq` holds 128 - T in every byte.  With six-bit values in eight-bit
 // fields neither v + (128 - T) - x nor (128 - T) - v + x leaves its byte, and bit 7 of the byte says
-// whether x <= v - T, respectively x >= v + T.  Returns bit 2 j = pixel c + j passed the dark test,
-// bit 2 j + 1 = it passed the bright test.
-__device__ __forceinline__ u32 fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0, u32 m1, u32 m2, u32 p0, u32 p1, u32 p2, u32 up3, u32 dn3, u32 kq) {
+// whether x <= v - T, respectively x >= v + T.  `xd` / `xb`: byte j = 1 iff pixel c + j passed the dark /
+// bright test (the caller turns four such bytes into four mask bits with one v_dot4).
+__device__ __forceinline__ void fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0, u32 m1, u32 m2, u32 p0, u32 p1, u32 p2, u32 up3, u32 dn3, u32 kq,
+                                                 u32& xd, u32& xb) {
     const u32 x4 = __builtin_amdgcn_alignbyte(c2, c1, 3), x12 = __builtin_amdgcn_alignbyte(c1, c0, 1);  // columns + 3 / - 3
     const u32 x2 = __builtin_amdgcn_alignbyte(p2, p1, 2), x14 = __builtin_amdgcn_alignbyte(p1, p0, 2);  // row + 2, columns + 2 / - 2
     const u32 x6 = __builtin_amdgcn_alignbyte(m2, m1, 2), x10 = __builtin_amdgcn_alignbyte(m1, m0, 2);  // row - 2
     const u32 vd = c1 + kq, vb = kq - c1;
     const u32 dark = ((vd - dn3) | (vd - up3)) & ((vd - x2) | (vd - x10)) & ((vd - x4) | (vd - x12)) & ((vd - x6) | (vd - x14));
     const u32 bright = ((vb + dn3) | (vb + up3)) & ((vb + x2) | (vb + x10)) & ((vb + x4) | (vb + x12)) & ((vb + x6) | (vb + x14));
-    const u32 w = ((dark >> 7) & 0x01010101u) | ((bright >> 6) & 0x02020202u);
-    return __builtin_amdgcn_udot4(w, 0x40100401u, 0u, false);
+    xd = (dark >> 7) & 0x01010101u;
+    xb = (bright >> 7) & 0x01010101u;
 }
 
 // The four dwords 2 * pair .. 2 * pair + 3 of a tile row (columns 8 * pair - 4 .. 8 * pair + 11 of the
@@ -688,14 +689,14 @@ const int min_thr = min(max(p.min_thr, 0), 255);
 // those rows start 16 banks apart (18 * 8 = 144 = 2 * 64 + 16), so the 8-byte reads of a half wave
 // fall on 64 different banks.
 const int pair = lane & 7, r_first = 2 * wave + (lane >> 5) + 8 * ((lane >> 3) & 3);
-u32 valid_bits = 0xFFFFFFFFu;
+u32 valid_bits = 0xFFFFu; // bit 8 * k + j: pixel j of row r_first + 32 * k lies inside the interior
 if (cur.iw < 64 || cur.ih < 64) { // a window cut by the image border (same decision in every thread)
     valid_bits = 0;
-    const u32 cols = (u32)((1ull << (2 * min(max(cur.iw - 8 * pair, 0), 8))) - 1ull);
+    const u32 cols = (1u << min(max(cur.iw - 8 * pair, 0), 8)) - 1u;
     #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (r_first + 32 * k < cur.ih) {
-            valid_bits |= cols << (16 * k);
+            valid_bits |= cols << (8 * k);
         }
     }
 }
@@ -710,15 +711,15 @@ for (int pass = 0; pass < 2; ++pass) {
         keep32[tid] = 0;
     }
     lds_barrier();
-    // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 2 * (8 * k + j)
-    // of `m` = pixel j (0..7) of row k passed the dark test, the next bit = it passed the bright
-    // test (one v_dot4 per side and strip turns four flag bytes into mask bits).  Survivors are
-    // appended to the work list: a wave prefix sum over the per-lane counts, one LDS atomic per
-    // wave, then every lane writes its own items.  An item is row << 6 | column, bit 12 = passed
-    // the dark test, bit 13 = the bright test.
+    // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 8 * k + j of `md` /
+    // `mbr` = pixel j (0..7) of row k passed the dark / bright test (one v_dot4 per side and strip
+    // turns four flag bytes into mask bits).  Survivors are appended to the work list: a wave prefix
+    // sum over the per-lane counts, one LDS atomic per wave, then every lane writes its own items,
+    // the dark-side ones first.  An item is row << 6 | column; bit 12 of a dark-side item = the pixel
+    // passed the bright test as well.
     {
         const u32 kq = (u32)(128 - ((thr + 1) >> 2)) * 0x01010101u;
-        u32 acc[2];
+        u32 accd[2], accb[2];
     #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int trow = r_first + 32 * k + 3;
@@ -728,15 +729,18 @@ for (int pass = 0; pass < 2; ++pass) {
             tile_row_quad(tile6, trow + 2, pair, pp);
             tile_row_quad(tile6, trow - 3, pair, u3);
             tile_row_quad(tile6, trow + 3, pair, d3);
-            const u32 a0 = fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq);
-            const u32 a1 = fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq);
-            acc[k] = a0 | (a1 << 8);
+            u32 xd0, xb0, xd1, xb1;
+            fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq, xd0, xb0);
+            fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq, xd1, xb1);
+            accd[k] = __builtin_amdgcn_udot4(xd1, 0x80402010u, __builtin_amdgcn_udot4(xd0, 0x08040201u, 0u, false), false);
+            accb[k] = __builtin_amdgcn_udot4(xb1, 0x80402010u, __builtin_amdgcn_udot4(xb0, 0x08040201u, 0u, false), false);
         }
-        const u32 m = (acc[0] | (acc[1] << 16)) & valid_bits;
-        const u32 md = m & 0x55555555u;               // passed the dark test (maybe both)
-        const u32 mb = (m >> 1) & ~m & 0x55555555u;   // passed the bright test only
-        u32 px = md | mb;
-        const int cnt = __popc(md) | (__popc(mb) << 16);
+        const u32 md = (accd[0] | (accd[1] << 8)) & valid_bits;   // passed the dark test (maybe both)
+        const u32 mbr = (accb[0] | (accb[1] << 8)) & valid_bits;  // passed the bright test (maybe both)
+        const u32 mb = mbr & ~md;                                 // the bright test only
+        const u32 both = mbr & md;
+        const int cnt_d = __popc(md);
+        const int cnt = cnt_d | (__popc(mb) << 16);
         const int incl = wave_incl_scan(cnt);
         const int wave_total = __builtin_amdgcn_readlane(incl, 63);
         if (wave_total) {
@@ -745,16 +749,23 @@ for (int pass = 0; pass < 2; ++pass) {
                 base = atomicAdd(&nwork, (u32)wave_total);
             }
             const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)base) + (u32)(incl - cnt);
-            u32 pos_d = first & 0xFFFFu, pos_b = 4095u - (first >> 16);
+            // the lane's item of rank i (dark-side ones first) goes to work[first_d + i] or, a
+            // bright-side one, to work[4095 - first_b - (i - cnt_d)]; as byte offsets with i2 = 2 i:
+            const u32 off_d = 2u * (first & 0xFFFFu);
+            const u32 end_b = 2u * (4095u - (first >> 16)) + 2u * (u32)cnt_d;
             const u32 item0 = ((u32)r_first << 6) | (8u * (u32)pair);
+            u32 px = md | (mb << 16); // bit q: dark-side item of pixel q, bit 16 + q: bright-side item
+            const u32 both12 = both << 12;
+            u32 i2 = 0;
             while (px) {
-                const u32 b = (u32)__builtin_ctz(px); // 2 * (8 * k + j)
+                const u32 b = (u32)__builtin_ctz(px);
                 px &= px - 1u;
-                const u32 dark = (md >> b) & 1u;
-                // k << 11 (row + 32 k) | j | side flags << 12
-                work[dark ? pos_d : pos_b] = (unsigned short)(item0 + ((b & 0x10u) << 7) + ((b >> 1) & 7u) + (((m >> b) & 3u) << 12));
-                pos_d += dark;
-                pos_b -= dark ^ 1u;
+                // pixel q = b & 15 = 8 k + j: row + 32 k, column + j
+                // (`both` has no bit above 15 and none at a bright-only pixel: shifting by b itself is enough)
+                const u32 it = (item0 | (b & 7u)) | ((b << 8) & 0x800u) | ((both12 >> b) & 0x1000u);
+                const u32 at = b < 16u ? off_d + i2 : end_b - i2;
+                *reinterpret_cast<unsigned short*>(reinterpret_cast<uint8_t*>(work) + at) = (unsigned short)it;
+                i2 += 2u;
             }
         }
     }
@@ -788,7 +799,7 @@ for (int pass = 0; pass < 2; ++pass) {
         int sc;
         if (i < n_dark) {
             sc = fast_dark_score(&tile[toff]) - 1;
-            if (item & 0x2000u) {
+            if (item & 0x1000u) {
                 // (the offset passes through an empty asm: otherwise the compiler hoists the bright
                 // score, which both arms contain, in front of the branch and every item pays for it)
                 int toff2 = toff;
