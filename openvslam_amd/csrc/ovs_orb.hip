@@ -602,10 +602,14 @@ __device__ __forceinline__ void fast_load_tile(const fast_item& it, int tid, int
         const int kk = lane - 18 * lr;
         const int r0 = wave * 3 + lr;
         const uint8_t* base = it.img + (long long)it.min_y * it.pitch + (it.min_x - 1) + 4 * kk;
+        // byte offsets of the rows r0, r0 + 12, ..., clamped to the window's last row: one multiplication
+        const u32 step = 12u * (u32)it.pitch, last = (u32)(it.th - 1) * (u32)it.pitch;
+        u32 off = (u32)r0 * (u32)it.pitch;
         u32 v[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            v[j] = *reinterpret_cast<const u32_unaligned*>(base + (u32)min(r0 + 12 * j, it.th - 1) * (u32)it.pitch);
+            v[j] = *reinterpret_cast<const u32_unaligned*>(base + min(off, last));
+            off += step;
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
