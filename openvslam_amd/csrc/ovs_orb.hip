@@ -437,17 +437,16 @@ __device__ __forceinline__ void fast_quick_flags(u32 c0, u32 c1, u32 c2, u32 m0,
 }
 
 // The four dwords 2 * pair .. 2 * pair + 3 of a tile row (columns 8 * pair - 4 .. 8 * pair + 11 of the
-// cell interior) as two aligned 8-byte LDS reads.  The address of the second read passes through an
-// empty asm so that the compiler keeps two ds_read_b64 (which the LDS serves conflict free for the lane
-// layout of stage A) instead of pairing them into one ds_read2_b64 (32 banks, twice the cycles).
-// (`tile` must be the __shared__ array itself so that both reads stay LDS instructions; the opaque
-// value is the byte offset, not the pointer.)
+// cell interior) as two aligned 8-byte LDS reads at byte offsets `lo` + 72 * trow and `hi` + 72 * trow,
+// lo = 8 * pair, hi = lo + 8.  The caller passes `hi` through an empty asm once, so that the compiler
+// cannot tell that the two reads are neighbours and keeps two ds_read_b64 (which the LDS serves
+// conflict free for the lane layout of stage A) instead of pairing them into one ds_read2_b64 (32
+// banks, twice the cycles).  (`tile` must be the __shared__ array itself so that both reads stay LDS
+// instructions; the opaque value is a byte offset, not a pointer.)
 template <typename Tile>
-__device__ __forceinline__ void tile_row_quad(Tile& tile, int trow, int pair, u32 (&d)[4]) {
-    const int off0 = trow * kTileStride + 8 * pair;
-    int off1 = off0 + 8;
-    asm volatile("" : "+v"(off1));
-    const uint2 a = *reinterpret_cast<const uint2*>(&tile[off0]), b = *reinterpret_cast<const uint2*>(&tile[off1]);
+__device__ __forceinline__ void tile_row_quad(Tile& tile, int trow, int lo, int hi, u32 (&d)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(&tile[trow * kTileStride + lo]);
+    const uint2 b = *reinterpret_cast<const uint2*>(&tile[trow * kTileStride + hi]);
     d[0] = a.x;
     d[1] = a.y;
     d[2] = b.x;
@@ -724,15 +723,19 @@ for (int pass = 0; pass < 2; ++pass) {
     {
         const u32 kq = (u32)(128 - ((thr + 1) >> 2)) * 0x01010101u;
         u32 accd[2], accb[2];
+        // byte offsets of the thread's two 8-byte columns in tile row r_first
+        const int lo = r_first * kTileStride + 8 * pair;
+        int hi = lo + 8;
+        asm volatile("" : "+v"(hi));
     #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int trow = r_first + 32 * k + 3;
+            const int trow = 32 * k + 3; // relative to r_first
             u32 c[4], mm[4], pp[4], u3[4], d3[4];
-            tile_row_quad(tile6, trow, pair, c);
-            tile_row_quad(tile6, trow - 2, pair, mm);
-            tile_row_quad(tile6, trow + 2, pair, pp);
-            tile_row_quad(tile6, trow - 3, pair, u3);
-            tile_row_quad(tile6, trow + 3, pair, d3);
+            tile_row_quad(tile6, trow, lo, hi, c);
+            tile_row_quad(tile6, trow - 2, lo, hi, mm);
+            tile_row_quad(tile6, trow + 2, lo, hi, pp);
+            tile_row_quad(tile6, trow - 3, lo, hi, u3);
+            tile_row_quad(tile6, trow + 3, lo, hi, d3);
             u32 xd0, xb0, xd1, xb1;
             fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq, xd0, xb0);
             fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq, xd1, xb1);
