@@ -309,12 +309,15 @@ int ovs_stereo_compute(const ovs_image_view* left_pyr, const ovs_image_view* rig
 
 /* The same on device-resident data: the two pyramids are the ones the extractor handles keep
  * after ovs_orb_extract_batch_dev (frame indices select the batch entries), keypoints / descriptors
- * / counts are the device outputs of those calls.  Enqueued on `stream`, not synchronised. */
+ * / counts are the device outputs of those calls.  Enqueued on `stream`, not synchronised.
+ * *d_status (device int32, may be NULL) becomes an OVS_ERR_* code when a keypoint's row, octave or
+ * patch falls outside the image (where the reference's cv::Mat range checks throw), else 0;
+ * with NULL such keypoints are skipped silently. */
 int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int frame_right,
                            const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_n_left,
                            const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_n_right, int cap,
                            float focal_x_baseline, float true_baseline,
-                           float* d_stereo_x_right, float* d_depths, int device, void* stream);
+                           float* d_stereo_x_right, float* d_depths, int32_t* d_status, int device, void* stream);
 
 /* stereo::compute for the live path: the two pyramids are the ones the extractor handles still
  * hold on the device after their last ovs_orb_extract (data/frame.cc:64-77 runs the two
@@ -430,7 +433,9 @@ typedef struct ovs_knn2 {
 
 /* Top-2 over the database for nq query descriptors (host query/result buffers). */
 int ovs_desc_db_search(ovs_desc_db* db, const uint8_t* queries, int nq, ovs_knn2* out);
-/* Device buffers, enqueued on `stream`. */
+/* Device buffers, enqueued on `stream`.  The per-slice partial results of a search live in one
+ * buffer of the handle: searches of one database must not overlap (one stream per handle at a time;
+ * attach the same device rows to a second handle to search them from a second stream). */
 int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ovs_knn2* d_out, void* stream);
 /* The search for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same

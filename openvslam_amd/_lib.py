@@ -88,7 +88,7 @@ def _declare(L):
     iv = C.POINTER(A.ImageView)
     L.ovs_stereo_compute.argtypes = [iv, iv, i, A.kpp, i, A.kpp, i, A.u8p, A.u8p, A.f32p, A.f32p,
                                      C.c_float, C.c_float, A.f32p, A.f32p, i]
-    L.ovs_stereo_compute_dev.argtypes = [vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, i, vp]
+    L.ovs_stereo_compute_dev.argtypes = [vp, i, vp, i, vp, vp, vp, vp, vp, vp, i, C.c_float, C.c_float, vp, vp, vp, i, vp]
     sz = C.c_size_t
     L.ovs_convert_to_grayscale_dev.argtypes = [vp, i, i, i, i, sz, sz, i, vp, sz, sz, i, vp]
     L.ovs_convert_to_grayscale.argtypes = [A.u8p, i, i, i, sz, i, A.u8p, sz, i]

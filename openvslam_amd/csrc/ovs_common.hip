@@ -92,21 +92,24 @@ static thread_local std::vector<std::string> g_order;
 
 bool timing_enabled() { return g_timing; }
 
-void timing_begin(const char* name, hipStream_t stream) {
+// Returns whether an entry was opened: timing_end must only close what its timing_begin opened
+// (otherwise the stop event of an earlier launch would be recorded a second time).
+bool timing_begin(const char* name, hipStream_t stream) {
     timing_pending p;
     p.name = name;
-    if (hipEventCreate(&p.start) != hipSuccess || hipEventCreate(&p.stop) != hipSuccess) {
-        return;
+    if (hipEventCreate(&p.start) != hipSuccess) {
+        return false;
+    }
+    if (hipEventCreate(&p.stop) != hipSuccess) {
+        (void)hipEventDestroy(p.start);
+        return false;
     }
     (void)hipEventRecord(p.start, stream);
     g_pending.push_back(p);
+    return true;
 }
 
-void timing_end(hipStream_t stream) {
-    if (!g_pending.empty()) {
-        (void)hipEventRecord(g_pending.back().stop, stream);
-    }
-}
+void timing_end(hipStream_t stream) { (void)hipEventRecord(g_pending.back().stop, stream); }
 
 static void timing_collect() {
     for (auto& p : g_pending) {

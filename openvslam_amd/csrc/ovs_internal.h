@@ -26,14 +26,14 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line);
 // Optional per-kernel timing: every launch made through OVS_LAUNCH is bracketed by two events on
 // its stream while timing is enabled on the calling thread.
 bool timing_enabled();
-void timing_begin(const char* name, hipStream_t stream);
+bool timing_begin(const char* name, hipStream_t stream);
 void timing_end(hipStream_t stream);
 
 #define OVS_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                   \
     do {                                                                            \
-        if (ovs::timing_enabled()) ovs::timing_begin(name, stream);                 \
+        const bool ovs_timed_ = ovs::timing_enabled() && ovs::timing_begin(name, stream); \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);        \
-        if (ovs::timing_enabled()) ovs::timing_end(stream);                         \
+        if (ovs_timed_) ovs::timing_end(stream);                                    \
     } while (0)
 
 // A growable device buffer owned by a handle.

@@ -563,7 +563,7 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
                            const ovs_keypoint* d_kps_left, const uint8_t* d_desc_left, const int32_t* d_n_left,
                            const ovs_keypoint* d_kps_right, const uint8_t* d_desc_right, const int32_t* d_n_right, int cap,
                            float focal_x_baseline, float true_baseline,
-                           float* d_stereo_x_right, float* d_depths, int device, void* stream_) {
+                           float* d_stereo_x_right, float* d_depths, int32_t* d_status, int device, void* stream_) {
     if (!left || !right || !d_kps_left || !d_desc_left || !d_n_left || !d_kps_right || !d_desc_right || !d_n_right || cap <= 0
         || !d_stereo_x_right || !d_depths) {
         return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
@@ -609,7 +609,8 @@ int ovs_stereo_compute_dev(ovs_orb* left, int frame_left, ovs_orb* right, int fr
     auto* d_row_start = cv.take<u32>(static_cast<size_t>(rows) + 1);
     auto* d_row_items = cv.take<u32>(items_cap);
     auto* d_corr = cv.take<int>(cap);
-    auto* d_err = cv.take<int>(1);
+    // the kernels' error word: the caller's, or (d_status == NULL: the caller does not want to know) a scratch word
+    int* d_err = d_status ? d_status : cv.take<int>(1);
     OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
     return launch_stereo(im, d_kps_left, d_desc_left, d_n_left, cap, d_kps_right, d_desc_right, d_n_right, cap, cap, focal_x_baseline, true_baseline,
                          d_row_start, d_row_items, items_cap, d_corr, d_err, d_stereo_x_right, d_depths, st);

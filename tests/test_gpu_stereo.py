@@ -113,11 +113,13 @@ def test_stereo_compute_dev_matches_oracle():
     xr = torch.zeros((cap,), dtype=torch.float32, device=dev)
     dep = torch.zeros((cap,), dtype=torch.float32, device=dev)
     true_baseline = np.float32(FXB / FX)
+    status1 = torch.full((1,), 77, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().ovs_stereo_compute_dev(exts[0]._h, 0, exts[1]._h, 0,
                                                  bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr(),
                                                  bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), bufs[1][3].data_ptr(), cap,
-                                                 np.float32(FXB), true_baseline, xr.data_ptr(), dep.data_ptr(), 0, stream))
+                                                 np.float32(FXB), true_baseline, xr.data_ptr(), dep.data_ptr(), status1.data_ptr(), 0, stream))
     torch.cuda.synchronize(dev)
+    assert int(status1.item()) == 0
     nl = int(bufs[0][3].item())
     ref_l, ref_r = oracle.OrbExtractor(max_num_keypts=n), oracle.OrbExtractor(max_num_keypts=n)
     kl, dl = ref_l.extract(left)
@@ -170,7 +172,7 @@ def test_stereo_batch_equals_pair_by_pair_and_oracle():
         dep1 = torch.zeros((cap,), dtype=torch.float32, device=dev)
         _lib.check(L.ovs_stereo_compute_dev(exts[0]._h, p, exts[1]._h, p, bufs[0][1][p].data_ptr(), bufs[0][2][p].data_ptr(), bufs[0][3][p:].data_ptr(),
                                             bufs[1][1][p].data_ptr(), bufs[1][2][p].data_ptr(), bufs[1][3][p:].data_ptr(), cap,
-                                            np.float32(FXB), true_baseline, xr1.data_ptr(), dep1.data_ptr(), 0, stream))
+                                            np.float32(FXB), true_baseline, xr1.data_ptr(), dep1.data_ptr(), None, 0, stream))
         torch.cuda.synchronize(dev)
         nl = int(counts[p])
         assert nl > 500
@@ -243,6 +245,45 @@ def test_stereo_out_of_range_row_is_reported():
         rc = getattr(lib_, prefix + "stereo_compute")(la, ra, 1, A.ptr(kp, A.kpp), 1, A.ptr(kp, A.kpp), 1, A.ptr(d, A.u8p), A.ptr(d, A.u8p),
                                                       A.ptr(sf, A.f32p), A.ptr(sf, A.f32p), 40.0, 0.1, A.ptr(out, A.f32p), A.ptr(out, A.f32p), *extra)
         assert rc == A.OVS_ERR_OUT_OF_RANGE
+
+
+def test_device_stereo_reports_out_of_range_keypoints():
+    """The single-pair device entry point hands the kernels' error word to the caller: a left keypoint
+    whose row band leaves the image gives OVS_ERR_OUT_OF_RANGE in *d_status (and 0 without it)."""
+    dev = torch.device("cuda", 0)
+    w, h, n = 320, 240, 300
+    frames = synth.make_sequence(w, h, 2, seed=12, dx=4, dy=0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    exts, bufs = [], []
+    for f in range(2):
+        ext = orb_extractor(orb_params(max_num_keypts=n), device=0)
+        cap = ext.keypoint_capacity(w, h)
+        d_img = torch.from_numpy(frames[f]).to(dev)
+        kps = torch.zeros((1, cap, 7), dtype=torch.float32, device=dev)
+        desc = torch.zeros((1, cap, 32), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        ext.extract_batch_dev(d_img.data_ptr(), 1, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), cnt.data_ptr(), cap, stream)
+        exts.append(ext)
+        bufs.append((d_img, kps, desc, cnt))
+    xr = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    dep = torch.zeros((cap,), dtype=torch.float32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    def run(d_status):
+        return _lib.lib().ovs_stereo_compute_dev(exts[0]._h, 0, exts[1]._h, 0, bufs[0][1].data_ptr(), bufs[0][2].data_ptr(), bufs[0][3].data_ptr(),
+                                                 bufs[1][1].data_ptr(), bufs[1][2].data_ptr(), bufs[1][3].data_ptr(), cap,
+                                                 np.float32(40.0), np.float32(0.1), xr.data_ptr(), dep.data_ptr(), d_status, 0, stream)
+
+    _lib.check(run(status.data_ptr()))
+    torch.cuda.synchronize(dev)
+    assert int(status.item()) == 0
+    # move the first right keypoint to the last image row: its row band (y +- 2 * scale) leaves the image
+    bufs[1][1][0, 0, 1] = float(h) - 0.5
+    _lib.check(run(status.data_ptr()))
+    torch.cuda.synchronize(dev)
+    assert int(status.item()) == A.OVS_ERR_OUT_OF_RANGE
+    _lib.check(run(None))
+    torch.cuda.synchronize(dev)
 
 
 def _unit(v):

@@ -197,6 +197,67 @@ def test_oracle_fisheye_clips_beyond_a_half_turn():
     assert np.isfinite(out["x"][0]) and np.isfinite(out["y"][0])
 
 
+def _scalar_radial_undistort(u, fx, cx, k1):
+    """cv::undistortPoints for a point on the x axis of a camera with one radial coefficient, as the
+    scalar recurrence the OpenCV loop reduces to (all tangential / rational / prism terms are 0 and y
+    stays 0):  x <- x0 / (1 + k1 x^2)  until the reprojection error |fx x (1 + k1 x^2) + cx - u| drops
+    below 1e-6 (checked before each iteration) or 20 iterations have run.  Plain Python doubles; every
+    omitted term is an exact + 0 or * 1.  Returns (pixel as float32, iterations run)."""
+    fx, cx, k1 = f32(fx), f32(cx), f32(k1)
+    x0 = (u - cx) * (1.0 / fx)
+    x, err, it = x0, float("inf"), 0
+    while it < 20 and not err < 1e-6:
+        r2 = x * x
+        icdist = 1.0 / (1.0 + k1 * r2)
+        assert icdist > 0
+        x = x0 * icdist
+        r2 = x * x
+        xd = x * (1.0 + k1 * r2)
+        e = (xd * fx + cx) - u
+        err = (e * e) ** 0.5
+        it += 1
+    return np.float32(fx * x + cx), it
+
+
+@pytest.mark.parametrize("u,k1,stops_on", [(400.0, -0.05, "eps"), (530.0, -0.3, "count")])
+def test_oracle_iteration_stops_on_eps_or_on_count(u, k1, stops_on):
+    """Known answers of the termination criterion (perspective.cc:115-116: COUNT 20 + EPS 1e-6): a mild
+    distortion converges in a few iterations and stops on EPS; a strong one near the fold of the model
+    is still moving after 20 iterations and stops on COUNT.  The recurrence above is evaluated by hand
+    (scalar code, not the vectorised restatement)."""
+    par = dict(fx=300.0, fy=300.0, cx=320.0, cy=240.0, k1=k1, cols=640, rows=480)
+    want, iterations = _scalar_radial_undistort(u, par["fx"], par["cx"], k1)
+    assert (iterations < 20) == (stops_on == "eps") and iterations >= 3
+    kps = np.zeros(1, A.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = u, par["cy"]
+    out = oracle_undistort(cam_struct(A.CAMERA_PERSPECTIVE, par), kps)
+    assert out["x"][0] == want and out["y"][0] == np.float32(par["cy"])
+    if stops_on == "count":
+        # one more iteration would have changed the float result: the count really is what stopped it
+        fx, cx = f32(par["fx"]), f32(par["cx"])
+        x0 = (u - cx) * (1.0 / fx)
+        x = (float(want) - cx) / fx
+        assert np.float32(fx * (x0 / (1.0 + f32(k1) * x * x)) + cx) != want
+
+
+def test_oracle_fisheye_clamp_known_answer():
+    """cv::fisheye::undistortPoints clips theta_d to pi / 2.  With all four coefficients 0 the Newton
+    loop leaves theta = theta_d (its first correction is exactly 0), so a pixel whose normalised radius
+    exceeds pi / 2 is scaled by tan(pi / 2) / (pi / 2) whatever its distance: the same huge factor for a
+    point just outside the limit and for one ten times farther out."""
+    import math
+    par = dict(fx=200.0, fy=200.0, cx=256.0, cy=256.0, k1=0.0, k2=0.0, k3=0.0, k4=0.0, cols=512, rows=512)
+    scale = math.tan(math.pi / 2) / (math.pi / 2)
+    kps = np.zeros(3, A.KEYPOINT_DTYPE)
+    kps["x"] = (256.0 + 200.0 * 1.6, 256.0 + 200.0 * 16.0, 256.0 + 200.0 * 1.5)   # radius 1.6, 16 and (inside) 1.5
+    kps["y"] = 256.0
+    out = oracle_undistort(cam_struct(A.CAMERA_FISHEYE, par), kps)
+    for i, r in ((0, 1.6), (1, 16.0)):
+        assert out["x"][i] == np.float32(200.0 * (r * scale) + 256.0) and out["y"][i] == np.float32(256.0)
+    # inside the limit nothing is clipped: x = fx tan(1.5) + cx
+    assert out["x"][2] == np.float32(200.0 * (1.5 * (math.tan(1.5) / 1.5)) + 256.0)
+
+
 GPU_CASES = [("perspective", KITTI, 20.0), ("perspective", EUROC, 20.0), ("perspective", STRONG, 300.0), ("fisheye", TUM_VI, 50.0)]
 
 
