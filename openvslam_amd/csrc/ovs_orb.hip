@@ -684,239 +684,239 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
     fast_load_tile(cur, tid, lane, wave, tile, tile6);
     lds_barrier();
 
-int thr = min(max(p.ini_thr, 0), 255);
-const int min_thr = min(max(p.min_thr, 0), 255);
-// stage A geometry of this thread: eight columns (two strips of four, `pair`) of the rows r_first and
-// r_first + 32; two mask bits per pixel, set for the pixels inside the interior.  The 32 lanes of a
-// half wave cover eight pairs of the rows r, r + 8, r + 16, r + 24: with 18 dwords per tile row
-// those rows start 16 banks apart (18 * 8 = 144 = 2 * 64 + 16), so the 8-byte reads of a half wave
-// fall on 64 different banks.
-const int pair = lane & 7, r_first = 2 * wave + (lane >> 5) + 8 * ((lane >> 3) & 3);
-u32 valid_bits = 0xFFFFu; // bit 8 * k + j: pixel j of row r_first + 32 * k lies inside the interior
-if (cur.iw < 64 || cur.ih < 64) { // a window cut by the image border (same decision in every thread)
-    valid_bits = 0;
-    const u32 cols = (1u << min(max(cur.iw - 8 * pair, 0), 8)) - 1u;
-    #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (r_first + 32 * k < cur.ih) {
-            valid_bits |= cols << (8 * k);
-        }
-    }
-}
-    #pragma unroll 1
-for (int pass = 0; pass < 2; ++pass) {
-    if (tid == 0) {
-        nwork = 0;
-        ncorner = 0;
-        total = 0;
-    }
-    if (tid < 128) {
-        keep32[tid] = 0;
-    }
-    lds_barrier();
-    // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 8 * k + j of `md` /
-    // `mbr` = pixel j (0..7) of row k passed the dark / bright test (one v_dot4 per side and strip
-    // turns four flag bytes into mask bits).  Survivors are appended to the work list: a wave prefix
-    // sum over the per-lane counts, one LDS atomic per wave, then every lane writes its own items,
-    // the dark-side ones first.  An item is row << 6 | column; bit 12 of a dark-side item = the pixel
-    // passed the bright test as well.
-    {
-        const u32 kq = (u32)(128 - ((thr + 1) >> 2)) * 0x01010101u;
-        u32 accd[2], accb[2];
-        // byte offsets of the thread's two 8-byte columns in tile row r_first
-        const int lo = r_first * kTileStride + 8 * pair;
-        int hi = lo + 8;
-        asm volatile("" : "+v"(hi));
-    #pragma unroll
+    int thr = min(max(p.ini_thr, 0), 255);
+    const int min_thr = min(max(p.min_thr, 0), 255);
+    // stage A geometry of this thread: eight columns (two strips of four, `pair`) of the rows r_first and
+    // r_first + 32; two mask bits per pixel, set for the pixels inside the interior.  The 32 lanes of a
+    // half wave cover eight pairs of the rows r, r + 8, r + 16, r + 24: with 18 dwords per tile row
+    // those rows start 16 banks apart (18 * 8 = 144 = 2 * 64 + 16), so the 8-byte reads of a half wave
+    // fall on 64 different banks.
+    const int pair = lane & 7, r_first = 2 * wave + (lane >> 5) + 8 * ((lane >> 3) & 3);
+    u32 valid_bits = 0xFFFFu; // bit 8 * k + j: pixel j of row r_first + 32 * k lies inside the interior
+    if (cur.iw < 64 || cur.ih < 64) { // a window cut by the image border (same decision in every thread)
+        valid_bits = 0;
+        const u32 cols = (1u << min(max(cur.iw - 8 * pair, 0), 8)) - 1u;
+        #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int trow = 32 * k + 3; // relative to r_first
-            u32 c[4], mm[4], pp[4], u3[4], d3[4];
-            tile_row_quad(tile6, trow, lo, hi, c);
-            tile_row_quad(tile6, trow - 2, lo, hi, mm);
-            tile_row_quad(tile6, trow + 2, lo, hi, pp);
-            tile_row_quad(tile6, trow - 3, lo, hi, u3);
-            tile_row_quad(tile6, trow + 3, lo, hi, d3);
-            u32 xd0, xb0, xd1, xb1;
-            fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq, xd0, xb0);
-            fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq, xd1, xb1);
-            accd[k] = __builtin_amdgcn_udot4(xd1, 0x80402010u, __builtin_amdgcn_udot4(xd0, 0x08040201u, 0u, false), false);
-            accb[k] = __builtin_amdgcn_udot4(xb1, 0x80402010u, __builtin_amdgcn_udot4(xb0, 0x08040201u, 0u, false), false);
-        }
-        const u32 md = (accd[0] | (accd[1] << 8)) & valid_bits;   // passed the dark test (maybe both)
-        const u32 mbr = (accb[0] | (accb[1] << 8)) & valid_bits;  // passed the bright test (maybe both)
-        const u32 mb = mbr & ~md;                                 // the bright test only
-        const u32 both = mbr & md;
-        const int cnt_d = __popc(md);
-        const int cnt = cnt_d | (__popc(mb) << 16);
-        const int incl = wave_incl_scan(cnt);
-        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
-        if (wave_total) {
-            u32 base = 0;
-            if (lane == 0) {
-                base = atomicAdd(&nwork, (u32)wave_total);
-            }
-            const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)base) + (u32)(incl - cnt);
-            // the lane's item of rank i (dark-side ones first) goes to work[first_d + i] or, a
-            // bright-side one, to work[4095 - first_b - (i - cnt_d)]; as byte offsets with i2 = 2 i:
-            const u32 off_d = 2u * (first & 0xFFFFu);
-            const u32 end_b = 2u * (4095u - (first >> 16)) + 2u * (u32)cnt_d;
-            const u32 item0 = ((u32)r_first << 6) | (8u * (u32)pair);
-            u32 px = md | (mb << 16); // bit q: dark-side item of pixel q, bit 16 + q: bright-side item
-            const u32 both12 = both << 12;
-            u32 i2 = 0;
-            while (px) {
-                const u32 b = (u32)__builtin_ctz(px);
-                px &= px - 1u;
-                // pixel q = b & 15 = 8 k + j: row + 32 k, column + j
-                // (`both` has no bit above 15 and none at a bright-only pixel: shifting by b itself is enough)
-                const u32 it = (item0 | (b & 7u)) | ((b << 8) & 0x800u) | ((both12 >> b) & 0x1000u);
-                const u32 at = b < 16u ? off_d + i2 : end_b - i2;
-                *reinterpret_cast<unsigned short*>(reinterpret_cast<uint8_t*>(work) + at) = (unsigned short)it;
-                i2 += 2u;
+            if (r_first + 32 * k < cur.ih) {
+                valid_bits |= cols << (8 * k);
             }
         }
     }
-    lds_barrier();
-    // the rejection test is done with the six-bit tile: its memory becomes the score plane, all zero
-    {
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        reinterpret_cast<uint4*>(score)[tid] = z;
-        if (tid < 315 - 256) {
-            reinterpret_cast<uint4*>(score)[256 + tid] = z;
+    #pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (tid == 0) {
+            nwork = 0;
+            ncorner = 0;
+            total = 0;
         }
-    }
-    lds_barrier();
-    // stage B: exact score of the survivors from the side that passed (a pixel that passed the
-    // test on one side only cannot reach the threshold on the other, so the side score
-    // decides; both sides for the rare pixel that passed both); below the threshold: 0.
-    // Item i < n_dark comes from the front of `work`, the others from its back: the threads of a
-    // wave take consecutive items, so all but one wave run one side's code only.
-    // Items that reach the threshold go to a second list in the unused middle of `work` (when the
-    // lists are short enough for that and for the third list below), the suppression pass then
-    // only walks those.
-    const u32 nwp = nwork;
-    const int n_dark = (int)(nwp & 0xFFFFu), nw = n_dark + (int)(nwp >> 16);
-    compact = nw <= kCompactMax;
-    unsigned short* corners = work + n_dark; // the unused middle of `work`: at least 4096 - nw entries
-    auto item_at = [&](int i) -> u32 { return i < n_dark ? work[i] : work[4095 - (i - n_dark)]; };
-    for (int i = tid; i < nw; i += 256) {
-        const u32 item = item_at(i);
-        const int r = (item >> 6) & 63, c = item & 63;
-        const int toff = (r + 3) * kTileStride + c + 4;
-        int sc;
-        if (i < n_dark) {
-            sc = fast_dark_score(&tile[toff]) - 1;
-            if (item & 0x1000u) {
-                // (the offset passes through an empty asm: otherwise the compiler hoists the bright
-                // score, which both arms contain, in front of the branch and every item pays for it)
-                int toff2 = toff;
-                asm volatile("" : "+v"(toff2));
-                sc = max(sc, fast_bright_score(&tile[toff2]) - 1);
+        if (tid < 128) {
+            keep32[tid] = 0;
+        }
+        lds_barrier();
+        // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 8 * k + j of `md` /
+        // `mbr` = pixel j (0..7) of row k passed the dark / bright test (one v_dot4 per side and strip
+        // turns four flag bytes into mask bits).  Survivors are appended to the work list: a wave prefix
+        // sum over the per-lane counts, one LDS atomic per wave, then every lane writes its own items,
+        // the dark-side ones first.  An item is row << 6 | column; bit 12 of a dark-side item = the pixel
+        // passed the bright test as well.
+        {
+            const u32 kq = (u32)(128 - ((thr + 1) >> 2)) * 0x01010101u;
+            u32 accd[2], accb[2];
+            // byte offsets of the thread's two 8-byte columns in tile row r_first
+            const int lo = r_first * kTileStride + 8 * pair;
+            int hi = lo + 8;
+            asm volatile("" : "+v"(hi));
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int trow = 32 * k + 3; // relative to r_first
+                u32 c[4], mm[4], pp[4], u3[4], d3[4];
+                tile_row_quad(tile6, trow, lo, hi, c);
+                tile_row_quad(tile6, trow - 2, lo, hi, mm);
+                tile_row_quad(tile6, trow + 2, lo, hi, pp);
+                tile_row_quad(tile6, trow - 3, lo, hi, u3);
+                tile_row_quad(tile6, trow + 3, lo, hi, d3);
+                u32 xd0, xb0, xd1, xb1;
+                fast_quick_flags(c[0], c[1], c[2], mm[0], mm[1], mm[2], pp[0], pp[1], pp[2], u3[1], d3[1], kq, xd0, xb0);
+                fast_quick_flags(c[1], c[2], c[3], mm[1], mm[2], mm[3], pp[1], pp[2], pp[3], u3[2], d3[2], kq, xd1, xb1);
+                accd[k] = __builtin_amdgcn_udot4(xd1, 0x80402010u, __builtin_amdgcn_udot4(xd0, 0x08040201u, 0u, false), false);
+                accb[k] = __builtin_amdgcn_udot4(xb1, 0x80402010u, __builtin_amdgcn_udot4(xb0, 0x08040201u, 0u, false), false);
+            }
+            const u32 md = (accd[0] | (accd[1] << 8)) & valid_bits;   // passed the dark test (maybe both)
+            const u32 mbr = (accb[0] | (accb[1] << 8)) & valid_bits;  // passed the bright test (maybe both)
+            const u32 mb = mbr & ~md;                                 // the bright test only
+            const u32 both = mbr & md;
+            const int cnt_d = __popc(md);
+            const int cnt = cnt_d | (__popc(mb) << 16);
+            const int incl = wave_incl_scan(cnt);
+            const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+            if (wave_total) {
+                u32 base = 0;
+                if (lane == 0) {
+                    base = atomicAdd(&nwork, (u32)wave_total);
+                }
+                const u32 first = (u32)__builtin_amdgcn_readfirstlane((int)base) + (u32)(incl - cnt);
+                // the lane's item of rank i (dark-side ones first) goes to work[first_d + i] or, a
+                // bright-side one, to work[4095 - first_b - (i - cnt_d)]; as byte offsets with i2 = 2 i:
+                const u32 off_d = 2u * (first & 0xFFFFu);
+                const u32 end_b = 2u * (4095u - (first >> 16)) + 2u * (u32)cnt_d;
+                const u32 item0 = ((u32)r_first << 6) | (8u * (u32)pair);
+                u32 px = md | (mb << 16); // bit q: dark-side item of pixel q, bit 16 + q: bright-side item
+                const u32 both12 = both << 12;
+                u32 i2 = 0;
+                while (px) {
+                    const u32 b = (u32)__builtin_ctz(px);
+                    px &= px - 1u;
+                    // pixel q = b & 15 = 8 k + j: row + 32 k, column + j
+                    // (`both` has no bit above 15 and none at a bright-only pixel: shifting by b itself is enough)
+                    const u32 it = (item0 | (b & 7u)) | ((b << 8) & 0x800u) | ((both12 >> b) & 0x1000u);
+                    const u32 at = b < 16u ? off_d + i2 : end_b - i2;
+                    *reinterpret_cast<unsigned short*>(reinterpret_cast<uint8_t*>(work) + at) = (unsigned short)it;
+                    i2 += 2u;
+                }
             }
         }
-        else {
-            sc = fast_bright_score(&tile[toff]) - 1;
+        lds_barrier();
+        // the rejection test is done with the six-bit tile: its memory becomes the score plane, all zero
+        {
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(score)[tid] = z;
+            if (tid < 315 - 256) {
+                reinterpret_cast<uint4*>(score)[256 + tid] = z;
+            }
         }
-        const bool corner = sc >= thr;
-        score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
-        if (compact && corner) {
-            corners[atomicAdd(&ncorner, 1)] = (unsigned short)item;
+        lds_barrier();
+        // stage B: exact score of the survivors from the side that passed (a pixel that passed the
+        // test on one side only cannot reach the threshold on the other, so the side score
+        // decides; both sides for the rare pixel that passed both); below the threshold: 0.
+        // Item i < n_dark comes from the front of `work`, the others from its back: the threads of a
+        // wave take consecutive items, so all but one wave run one side's code only.
+        // Items that reach the threshold go to a second list in the unused middle of `work` (when the
+        // lists are short enough for that and for the third list below), the suppression pass then
+        // only walks those.
+        const u32 nwp = nwork;
+        const int n_dark = (int)(nwp & 0xFFFFu), nw = n_dark + (int)(nwp >> 16);
+        compact = nw <= kCompactMax;
+        unsigned short* corners = work + n_dark; // the unused middle of `work`: at least 4096 - nw entries
+        auto item_at = [&](int i) -> u32 { return i < n_dark ? work[i] : work[4095 - (i - n_dark)]; };
+        for (int i = tid; i < nw; i += 256) {
+            const u32 item = item_at(i);
+            const int r = (item >> 6) & 63, c = item & 63;
+            const int toff = (r + 3) * kTileStride + c + 4;
+            int sc;
+            if (i < n_dark) {
+                sc = fast_dark_score(&tile[toff]) - 1;
+                if (item & 0x1000u) {
+                    // (the offset passes through an empty asm: otherwise the compiler hoists the bright
+                    // score, which both arms contain, in front of the branch and every item pays for it)
+                    int toff2 = toff;
+                    asm volatile("" : "+v"(toff2));
+                    sc = max(sc, fast_bright_score(&tile[toff2]) - 1);
+                }
+            }
+            else {
+                sc = fast_bright_score(&tile[toff]) - 1;
+            }
+            const bool corner = sc >= thr;
+            score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
+            if (compact && corner) {
+                corners[atomicAdd(&ncorner, 1)] = (unsigned short)item;
+            }
         }
-    }
-    lds_barrier();
-    // non-maximum suppression (every pixel that is not on the list scores 0); in compact mode
-    // the kept items are collected from the end of `work` downwards (the bright-side items there
-    // are not read any more; dark + corner + kept items together stay below 4096 entries)
-    const int nms_n = compact ? ncorner : nw;
-    for (int i = tid; i < nms_n; i += 256) {
-        const u32 item = compact ? (u32)corners[i] : item_at(i);
-        const int r = (item >> 6) & 63, c = item & 63;
-        const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
-        const int sc = sp[0];
-        if (sc >= thr) {
-            int m = 0;
-    #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-    #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dy != 0 || dx != 0) {
-                        m = max(m, (int)sp[dy * 68 + dx]);
+        lds_barrier();
+        // non-maximum suppression (every pixel that is not on the list scores 0); in compact mode
+        // the kept items are collected from the end of `work` downwards (the bright-side items there
+        // are not read any more; dark + corner + kept items together stay below 4096 entries)
+        const int nms_n = compact ? ncorner : nw;
+        for (int i = tid; i < nms_n; i += 256) {
+            const u32 item = compact ? (u32)corners[i] : item_at(i);
+            const int r = (item >> 6) & 63, c = item & 63;
+            const uint8_t* sp = &score[(r + 1) * 68 + c + 1];
+            const int sc = sp[0];
+            if (sc >= thr) {
+                int m = 0;
+                #pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    #pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (dy != 0 || dx != 0) {
+                            m = max(m, (int)sp[dy * 68 + dx]);
+                        }
+                    }
+                }
+                if (sc > m) {
+                    atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
+                    const int k = atomicAdd(&total, 1);
+                    if (compact) {
+                        work[4095 - k] = (unsigned short)item;
                     }
                 }
             }
-            if (sc > m) {
-                atomicOr(&keep32[2 * r + (c >> 5)], 1u << (c & 31));
-                const int k = atomicAdd(&total, 1);
-                if (compact) {
-                    work[4095 - k] = (unsigned short)item;
+        }
+        lds_barrier();
+        if (total != 0 || pass == 1 || min_thr == thr) {
+            break;
+        }
+        thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
+        for (int i = tid; i < 70 * 18; i += 256) {
+            reinterpret_cast<u32*>(&tile6[0])[i] = (reinterpret_cast<const u32*>(&tile[0])[i] >> 2) & 0x3F3F3F3Fu;
+        }
+        lds_barrier();
+    }
+    if (total == 0) {
+        if (tid == 0) {
+            cell_counts[cur.out_cell] = 0;
+        }
+        return;
+    }
+
+    // the kept items (end of `work` downwards), or every survivor of the rejection test (both ends of `work`)
+    const int n_dark_f = (int)(nwork & 0xFFFFu);
+    const int n_items = compact ? total : n_dark_f + (int)(nwork >> 16);
+    auto final_item = [&](int i) -> u32 { return compact ? work[4095 - i] : (i < n_dark_f ? work[i] : work[4095 - (i - n_dark_f)]); };
+    if (s.mask) {
+        // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
+        for (int i = tid; i < n_items; i += 256) {
+            const u32 item = final_item(i);
+            const int r = (item >> 6) & 63, c = item & 63;
+            if ((keep32[2 * r + (c >> 5)] >> (c & 31)) & 1u) {
+                const unsigned y = kBorder + cur.ci * kCell + 3 + r;
+                const unsigned x = kBorder + cur.cj * kCell + 3 + c;
+                if (mask_is_zero(s, y, x, cur.scale)) {
+                    atomicAnd(&keep32[2 * r + (c >> 5)], ~(1u << (c & 31)));
                 }
             }
         }
+        lds_barrier();
     }
-    lds_barrier();
-    if (total != 0 || pass == 1 || min_thr == thr) {
-        break;
-    }
-    thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
-    for (int i = tid; i < 70 * 18; i += 256) {
-        reinterpret_cast<u32*>(&tile6[0])[i] = (reinterpret_cast<const u32*>(&tile[0])[i] >> 2) & 0x3F3F3F3Fu;
-    }
-    lds_barrier();
-}
-if (total == 0) {
-    if (tid == 0) {
-        cell_counts[cur.out_cell] = 0;
-    }
-    return;
-}
 
-// the kept items (end of `work` downwards), or every survivor of the rejection test (both ends of `work`)
-const int n_dark_f = (int)(nwork & 0xFFFFu);
-const int n_items = compact ? total : n_dark_f + (int)(nwork >> 16);
-auto final_item = [&](int i) -> u32 { return compact ? work[4095 - i] : (i < n_dark_f ? work[i] : work[4095 - (i - n_dark_f)]); };
-if (s.mask) {
-    // per-keypoint mask test, orb_extractor.cc:362 (after the emptiness test)
-    for (int i = tid; i < n_items; i += 256) {
-        const u32 item = final_item(i);
-        const int r = (item >> 6) & 63, c = item & 63;
-        if ((keep32[2 * r + (c >> 5)] >> (c & 31)) & 1u) {
-            const unsigned y = kBorder + cur.ci * kCell + 3 + r;
-            const unsigned x = kBorder + cur.cj * kCell + 3 + c;
-            if (mask_is_zero(s, y, x, cur.scale)) {
-                atomicAnd(&keep32[2 * r + (c >> 5)], ~(1u << (c & 31)));
-            }
+    if (wave == 0) {
+        const uint2 kr = reinterpret_cast<const uint2*>(keep32)[lane];
+        const int cnt = __popc(kr.x) + __popc(kr.y);
+        const int inc = wave_incl_scan(cnt);
+        rowbase[lane] = inc - cnt;
+        if (lane == 63) {
+            rowbase[64] = inc;
         }
     }
     lds_barrier();
-}
 
-if (wave == 0) {
-    const uint2 kr = reinterpret_cast<const uint2*>(keep32)[lane];
-    const int cnt = __popc(kr.x) + __popc(kr.y);
-    const int inc = wave_incl_scan(cnt);
-    rowbase[lane] = inc - cnt;
-    if (lane == 63) {
-        rowbase[64] = inc;
+    // raster order: position = keypoints in the rows above + kept pixels to the left in the row
+    u32* out = slots + cur.out_cell * kSlotsPerCell;
+    for (int i = tid; i < n_items; i += 256) {
+        const u32 item = final_item(i);
+        const int r = (item >> 6) & 63, c = item & 63;
+        const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
+        if ((bits >> c) & 1ull) {
+            const int pos = rowbase[r] + __popcll(bits & ((1ull << c) - 1ull));
+            const u32 x = cur.cj * kCell + 3 + c; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
+            const u32 y = cur.ci * kCell + 3 + r;
+            out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + c + 1] << 24);
+        }
     }
-}
-lds_barrier();
-
-// raster order: position = keypoints in the rows above + kept pixels to the left in the row
-u32* out = slots + cur.out_cell * kSlotsPerCell;
-for (int i = tid; i < n_items; i += 256) {
-    const u32 item = final_item(i);
-    const int r = (item >> 6) & 63, c = item & 63;
-    const u64 bits = (u64)keep32[2 * r] | ((u64)keep32[2 * r + 1] << 32);
-    if ((bits >> c) & 1ull) {
-        const int pos = rowbase[r] + __popcll(bits & ((1ull << c) - 1ull));
-        const u32 x = cur.cj * kCell + 3 + c; // keypt.pt.x += j * cell_size, orb_extractor.cc:359
-        const u32 y = cur.ci * kCell + 3 + r;
-        out[pos] = x | (y << 12) | ((u32)score[(r + 1) * 68 + c + 1] << 24);
+    if (tid == 0) {
+        cell_counts[cur.out_cell] = rowbase[64];
     }
-}
-if (tid == 0) {
-    cell_counts[cur.out_cell] = rowbase[64];
-}
 
 }
 
