@@ -1031,11 +1031,20 @@ __device__ __forceinline__ blur_row blur_row_finish(const blur_raw& w, u32 shift
     const u32 e = w.e[0] | (w.e[1] << 8) | (w.e[2] << 16) | (w.e[3] << 24);
     const u32 l = dpp_from_left(c, e);
     const u32 r = dpp_from_right(c, e);
+    // The window of output column j (0..3) is bytes j + 1 .. j + 7 of the twelve bytes (l, c, r): instead of
+    // cutting it out with v_alignbyte, the taps are laid over the three dwords as they are (weights of
+    // bytes outside the window are 0), which takes 2 + 3 + 3 + 2 v_dot4 for the four columns and no shifts.
+    constexpr u32 k0 = 18, k1 = 34, k2 = 49, k3 = 55;
+    constexpr u32 kL0 = (k0 << 8) | (k1 << 16) | (k2 << 24), kC0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
+    constexpr u32 kL1 = (k0 << 16) | (k1 << 24), kC1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), kR1 = k0;
+    constexpr u32 kL2 = (k0 << 24), kC2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), kR2 = k1 | (k0 << 8);
+    constexpr u32 kC3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), kR3 = k2 | (k1 << 8) | (k0 << 16);
+    static_assert(kC3 == kWa && kR3 == kWb, "column 3 is the unshifted window");
     blur_row out;
-    out.h[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 1), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 1), kWa, 0u, false), false);
-    out.h[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 2), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 2), kWa, 0u, false), false);
-    out.h[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(r, c, 3), kWb, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, l, 3), kWa, 0u, false), false);
-    out.h[3] = __builtin_amdgcn_udot4(r, kWb, __builtin_amdgcn_udot4(c, kWa, 0u, false), false);
+    out.h[0] = __builtin_amdgcn_udot4(c, kC0, __builtin_amdgcn_udot4(l, kL0, 0u, false), false);
+    out.h[1] = __builtin_amdgcn_udot4(r, kR1, __builtin_amdgcn_udot4(c, kC1, __builtin_amdgcn_udot4(l, kL1, 0u, false), false), false);
+    out.h[2] = __builtin_amdgcn_udot4(r, kR2, __builtin_amdgcn_udot4(c, kC2, __builtin_amdgcn_udot4(l, kL2, 0u, false), false), false);
+    out.h[3] = __builtin_amdgcn_udot4(r, kR3, __builtin_amdgcn_udot4(c, kC3, 0u, false), false);
     return out;
 }
 
