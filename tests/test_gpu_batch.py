@@ -82,6 +82,38 @@ def test_batch_extract_and_match(w, h, n_kp, n_frames, rects):
         assert k["y"].min() >= 0.1 * h - 1 and k["y"].max() <= 0.84 * h + 1
 
 
+def test_more_frames_than_one_grid_dimension_holds():
+    """The FAST kernel takes the frame from grid y, which is limited to 65535: a larger batch is cut into
+    several launches.  65 540 small frames (16 distinct images, repeated); the frames around the cut and
+    the last one are compared with the oracle, every repetition of an image with its first occurrence."""
+    dev = torch.device("cuda", 0)
+    w = h = 72
+    n_frames, distinct = 65540, 16
+    base = synth.make_sequence(w, h, distinct, seed=41, dx=5, dy=3)
+    frames = torch.from_numpy(base).to(dev).repeat((n_frames + distinct - 1) // distinct, 1, 1)[:n_frames].contiguous()
+    params = dict(max_num_keypts=60, num_levels=2, ini_fast_thr=12, min_fast_thr=5)
+    ext = orb_extractor(orb_params(**params), device=0)
+    cap = ext.keypoint_capacity(w, h)
+    kps = torch.zeros((n_frames, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_frames, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ext.extract_batch_dev(frames.data_ptr(), n_frames, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap, stream)
+    torch.cuda.synchronize(dev)
+    ref = oracle.OrbExtractor(**params)
+    for f in (0, 1, 65534, 65535, 65536, n_frames - 1):
+        k, d = ref.extract(base[f % distinct])
+        assert len(k) > 5
+        assert int(counts[f]) == len(k), f
+        got = kps[f, :len(k)].cpu().numpy().view(np.uint8).reshape(len(k), 28)
+        assert np.array_equal(got, k.view(np.uint8).reshape(len(k), 28)), "frame %d keypoints differ" % f
+        assert np.array_equal(desc[f, :len(k)].cpu().numpy(), d), "frame %d descriptors differ" % f
+    first = counts[:distinct]
+    assert torch.equal(counts, first.repeat((n_frames + distinct - 1) // distinct)[:n_frames])
+    rep = kps.view(torch.int32)[:distinct].repeat((n_frames + distinct - 1) // distinct, 1, 1)[:n_frames]
+    assert torch.equal(kps.view(torch.int32), rep)
+
+
 @pytest.mark.parametrize("w,h,base_off,pad", [(641, 479, 1, 0), (1241, 376, 3, 5), (322, 247, 2, 1), (640, 480, 0, 0)])
 def test_unaligned_caller_images(w, h, base_off, pad):
     """Level-0 images that start at any byte, with any row stride, and end exactly at the end of
