@@ -1806,14 +1806,24 @@ __device__ __forceinline__ float trig_sin(float v) {
 
 constexpr int kKpGroup = 16; // lanes per keypoint in k_orient_desc
 
-template <int W>
-__device__ __forceinline__ int group_sum_i32(int v) {
-#pragma unroll
-    for (int d = W / 2; d >= 1; d >>= 1) {
-        v += __shfl_xor(v, d, W);
-    }
+// Sum over the 16 lanes of a DPP row, returned in every lane: four rotations inside the row
+// (no LDS round trip, unlike ds_bpermute based shuffles).
+__device__ __forceinline__ int row16_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false); // row_ror:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false); // row_ror:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false); // row_ror:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false); // row_ror:1
     return v;
 }
+// Inclusive prefix sum over the 16 lanes of a DPP row (shifts that fill with 0).
+__device__ __forceinline__ int row16_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true); // row_shr:8
+    return v;
+}
+static_assert(kKpGroup == 16, "a keypoint's lane group is one DPP row");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1857,16 +1867,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     // oi - before(level) of the level whose running count first exceeds oi.  Per-level counts:
     // one lane per level (num_levels <= 16 = group width), inclusive scan over the group.
     const int myc = gl < p.num_levels ? lvl_count[frame * p.num_levels + gl] : 0;
-    const int bad = group_sum_i32<kKpGroup>(myc < 0 ? 1 : 0);
-    int incl = max(myc, 0);
-#pragma unroll
-    for (int d = 1; d < kKpGroup; d <<= 1) {
-        const int t = __shfl_up(incl, d, kKpGroup);
-        if (gl >= d) {
-            incl += t;
-        }
-    }
-    const int total = __shfl(incl, kKpGroup - 1, kKpGroup);
+    const int bad = row16_sum_i32(myc < 0 ? 1 : 0);
+    const int incl = row16_incl_scan_i32(max(myc, 0));
+    const int total = row16_sum_i32(max(myc, 0));
     const int oi = fblk * (256 / kKpGroup) + grp;
     if (oi == 0 && gl == 0) {
         // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
@@ -1905,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     // level = number of levels whose inclusive count is <= oi
     const u64 le = __ballot(gl < p.num_levels && incl <= oi);
     const int level = __popc((u32)(le >> (16 * (threadIdx.x >> 4 & 3))) & 0xFFFFu);
-    const int before = level == 0 ? 0 : __shfl(incl, level - 1, kKpGroup);
+    const int before = row16_sum_i32(gl < level ? max(myc, 0) : 0); // keypoints of the lower levels
     const level_geom& g = p.lv[level];
     const int j = g.kp_base + (oi - before); // slot in the per-frame level-keypoint arrays
 
@@ -1966,8 +1969,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
         m10 += s1 - (16 + (int)mis) * s0; // u = window byte index - 16 - mis
         m01 += v * s0;
     }
-    m10 = group_sum_i32<kKpGroup>(m10);
-    m01 = group_sum_i32<kKpGroup>(m01);
+    m10 = row16_sum_i32(m10);
+    m01 = row16_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     const float arad = (float)((double)angle * 3.14159265358979323846 / 180.0);
     const float ca = trig_cos(arad), sa = trig_sin(arad);
