@@ -458,14 +458,7 @@ __global__ __launch_bounds__(64) void k_landmark_median(const uint8_t* __restric
             own[t] = bin < 264 ? hist[bin] : 0u;
             sum += own[t];
         }
-        u32 inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(inc, d);
-            if (lane >= d) {
-                inc += t;
-            }
-        }
+        const u32 inc = wave_incl_scan_u32(sum);
         u32 run = inc - sum; // elements in lower bins
         u32 median = 0xFFFFFFFFu;
 #pragma unroll

@@ -84,6 +84,18 @@ __device__ __forceinline__ u32 group_sum_u32(u32 v) {
 }
 
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) { return group_sum_u32<64>(v); }
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (no LDS round trips).
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+    return (u32)v;
+}
 __device__ __forceinline__ u64 wave_min_u64(u64 v) { return group_min_u64<64>(v); }
 
 __device__ __forceinline__ int cv_floor_dd(double v) {

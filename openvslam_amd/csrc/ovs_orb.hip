@@ -1240,14 +1240,7 @@ __device__ u32 block_excl_scan(u32* a, int n, u32* red) {
     for (int i = b; i < e; ++i) {
         sum += a[i];
     }
-    u32 inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 t = __shfl_up(inc, d);
-        if (lane >= d) {
-            inc += t;
-        }
-    }
+    const u32 inc = (u32)wave_incl_scan((int)sum);
     __syncthreads(); // red may still be read by a previous call
     if (lane == 63) {
         red[wave] = inc;

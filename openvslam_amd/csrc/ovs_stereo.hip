@@ -82,14 +82,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
         for (int i = b; i < e; ++i) {
             sum += cnt[i];
         }
-        u32 inc = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const u32 t = __shfl_up(inc, d);
-            if (lane >= d) {
-                inc += t;
-            }
-        }
+        const u32 inc = wave_incl_scan_u32(sum);
         if (lane == 63) {
             red[wave] = inc;
         }
