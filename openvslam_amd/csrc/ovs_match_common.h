@@ -76,6 +76,12 @@ __device__ __forceinline__ u32 group_min_u32(u32 v) {
 
 template <int W>
 __device__ __forceinline__ u32 group_sum_u32(u32 v) {
+    if (W == 8) { // the same three DPP operands as group_min_u32
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+        v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
+        return v;
+    }
 #pragma unroll
     for (int d = W / 2; d >= 1; d >>= 1) {
         v += __shfl_xor(v, d, W);

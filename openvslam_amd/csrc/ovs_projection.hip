@@ -571,15 +571,31 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
             e = f.cell_start[cx * R + w.max_cy + 1];
         }
         const u32 len = e - s;
-        u32 inc = len;
-#pragma unroll
-        for (int d = 1; d < G; d <<= 1) {
-            const u32 t = __shfl_up(inc, d, G);
-            if (gl >= d) {
-                inc += t;
-            }
+        // inclusive prefix over the group's lanes and its total, without LDS round trips: a whole wave
+        // uses the wave scan, a group of up to 16 lanes row shifts masked at the group boundary
+        static_assert(G == 64 || G <= 16, "a query's lane group is the wave or lies inside one DPP row");
+        u32 inc = len, T;
+        if (G == 64) {
+            inc = wave_incl_scan_u32(len);
+            T = (u32)__builtin_amdgcn_readlane((int)inc, 63);
         }
-        const u32 T = __shfl(inc, G - 1, G);
+        else {
+            u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true); // row_shr:1
+            inc += gl >= 1 ? t : 0u;
+            if (G > 2) {
+                t = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true); // row_shr:2
+                inc += gl >= 2 ? t : 0u;
+            }
+            if (G > 4) {
+                t = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true); // row_shr:4
+                inc += gl >= 4 ? t : 0u;
+            }
+            if (G > 8) {
+                t = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true); // row_shr:8
+                inc += gl >= 8 ? t : 0u;
+            }
+            T = group_sum_u32<G>(len);
+        }
         const u32 exc = inc - len;
         for (u32 t0 = 0; t0 < T; t0 += G) {
             const u32 t = t0 + gl;
