@@ -1266,6 +1266,25 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
     return (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
 }
 
+// ctr[target] += 1 for every lane with `valid`, for counters that many lanes of a wave hit at once (the
+// first passes of a level have a handful of nodes for thousands of candidates, and LDS atomics on one
+// address are served one lane at a time): the wave peels off one distinct target per round and its
+// first lane adds the number of lanes that share it.  Called by all lanes of the wave.
+__device__ __forceinline__ void lds_count_aggregated(u32* ctr, u32 target, bool valid) {
+    u64 todo = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const u32 t = (u32)__builtin_amdgcn_readlane((int)target, leader);
+        const u64 same = __ballot(valid && target == t);
+        if (lane == leader) {
+            atomicAdd(&ctr[t], (u32)__popcll(same));
+        }
+        todo &= ~same;
+    }
+}
+constexpr int kAggregateBelow = 32; // counters: above this the lanes of a wave rarely meet
+
 // Candidate record: x | y << 16 in one array (written once), response << 24 | current node id in a
 // second one (rewritten by every sweep: a wave's 64 records are 256 contiguous bytes, whole cache
 // lines, where an interleaved layout would rewrite half of every line).
@@ -1305,8 +1324,10 @@ __device__ __forceinline__ void for_each_candidate(const u32* __restrict__ cnode
 //   stage2(n, rec, b, aux, x, y)   the new node id (may read one more LDS word)
 template <typename Stage1, typename Stage2>
 __device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* __restrict__ cnode, int N, const u32* nc_from, const short4* nb_from,
-                                              const u32* nc_to, const short4* nb_to, u32* votes, Stage1&& stage1, Stage2&& stage2) {
+                                              const u32* nc_to, const short4* nb_to, u32* votes, int n_votes, Stage1&& stage1, Stage2&& stage2) {
+    // n_votes = number of vote counters of this pass (the same in every thread)
     const int tid = threadIdx.x, nt = blockDim.x;
+    const bool aggregate = n_votes <= kAggregateBelow;
     for (int i0 = tid; i0 < N; i0 += kCandDepth * nt) {
         uint2 cd[kCandDepth];
 #pragma unroll
@@ -1337,11 +1358,16 @@ __device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* 
 #pragma unroll
         for (int u = 0; u < kCandDepth; ++u) {
             const int i = i0 + u * nt;
+            const bool votes_now = i < N && !(rec2[u] & kLeaf);
+            const u32 target = 4 * nn[u] + child_of(b2[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16));
             if (i < N) {
                 cnode[i] = (cd[u].y & 0xFF000000u) | nn[u];
-                if (!(rec2[u] & kLeaf)) {
-                    atomicAdd(&votes[4 * nn[u] + child_of(b2[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16))], 1u);
-                }
+            }
+            if (aggregate) {
+                lds_count_aggregated(votes, target, votes_now);
+            }
+            else if (votes_now) {
+                atomicAdd(&votes[target], 1u);
             }
         }
     }
@@ -1448,10 +1474,17 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u * nt < N) {
+            const bool valid = i0 + u * nt < N;
+            if (valid) {
                 const u32 x = v[u] & 0xFFFu, y = (v[u] >> 12) & 0xFFFu, r = v[u] >> 24;
                 cxy[idx[u]] = x | (y << 16);
                 cnode[idx[u]] = (r << 24) | ni[u];
+            }
+            // (a level starts with one node per image-aspect unit: a handful of counters for all candidates)
+            if (n0 <= kAggregateBelow) {
+                lds_count_aggregated(t0, ni[u], valid);
+            }
+            else if (valid) {
                 atomicAdd(&t0[ni[u]], 1u);
             }
         }
@@ -1481,7 +1514,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     __syncthreads();
     // compact node ids + votes for the first sweep
     move_and_vote(
-        cxy, cnode, N, t1, nb_cur, nc_cur, nb_cur, cc, [&](u32) { return 0u; },
+        cxy, cnode, N, t1, nb_cur, nc_cur, nb_cur, cc, 4 * S, [&](u32) { return 0u; },
         [&](u32, u32 compact_id, short4, u32, int, int) { return compact_id; });
     __syncthreads();
 
@@ -1546,7 +1579,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         __syncthreads();
         // move every candidate to its child and vote for the next split of that child
         move_and_vote(
-            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32) { return 0u; },
+            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, 4 * Snew, [&](u32) { return 0u; },
             [&](u32 n, u32 rec, short4 b, u32, int x, int y) { return cc[4 * n + ((rec & kLeaf) ? 0 : child_of(b, x, y))]; });
         const int pool = (int)sh[0];
         __syncthreads();
@@ -1668,7 +1701,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         }
         __syncthreads();
         move_and_vote(
-            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, [&](u32 n) { return t3[n]; },
+            cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, 4 * Snew, [&](u32 n) { return t3[n]; },
             [&](u32 n, u32 rec, short4 b, u32 kept_before, int x, int y) {
                 const u32 child_id = cc[4 * n + ((rec & kProc) ? child_of(b, x, y) : 0)];
                 return (rec & kProc) ? child_id : (u32)Cn + kept_before;
