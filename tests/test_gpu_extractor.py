@@ -163,3 +163,36 @@ def test_extract_from_strided_host_buffers():
     # and both equal the oracle
     rk, rd = oracle.OrbExtractor(max_num_keypts=700).extract(img, mask)
     assert np.array_equal(rk.view(np.uint8), want_k.view(np.uint8)) and np.array_equal(rd, want_d)
+
+
+def test_repeated_single_frame_calls_on_one_handle():
+    """One handle through a live session: ten different frames, then a new threshold, another image size,
+    a caller mask and the first size again, then a new keypoint target.  Every result equals the oracle's
+    for that frame and those parameters (staging buffers, plan and constants are reused or rebuilt as
+    needed between the calls)."""
+    def check(ext, img, mask=None, **params):
+        ref = oracle.OrbExtractor(**params)
+        rk, rd = ref.extract(img, mask)
+        gk, gd = ext.extract(img, mask)
+        assert len(gk) == len(rk) and len(rk) > 100
+        assert np.array_equal(gk.view(np.uint8), rk.view(np.uint8)) and np.array_equal(gd, rd)
+        assert np.array_equal(ext.image_pyramid(3), ref.pyramid_level(3))
+
+    ext = orb_extractor(orb_params(max_num_keypts=800))
+    frames = synth.make_sequence(640, 480, 10, seed=21, dx=7, dy=2)
+    for f in frames:
+        check(ext, f, max_num_keypts=800)
+    ext.set_initial_fast_threshold(35)
+    for f in frames[:4]:
+        check(ext, f, max_num_keypts=800, ini_fast_thr=35)
+    small = synth.make_sequence(400, 300, 4, seed=22, dx=3, dy=3)
+    for f in small:
+        check(ext, f, max_num_keypts=800, ini_fast_thr=35)
+    mask = np.full((300, 400), 255, dtype=np.uint8)
+    mask[:, :150] = 0
+    check(ext, small[0], mask, max_num_keypts=800, ini_fast_thr=35)
+    for f in small[:3]:
+        check(ext, f, max_num_keypts=800, ini_fast_thr=35)
+    ext.set_max_num_keypoints(500)
+    for f in frames[:4]:
+        check(ext, f, max_num_keypts=500, ini_fast_thr=35)
