@@ -729,6 +729,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
             asm volatile("" : "+v"(hi));
             #pragma unroll
             for (int k = 0; k < 2; ++k) {
+                accd[k] = 0;
+                accb[k] = 0;
+                if (k == 1 && cur.ih <= 32) {
+                    continue; // a window of at most 32 rows (bottom edge of a level): no thread has a second row
+                }
                 const int trow = 32 * k + 3; // relative to r_first
                 u32 c[4], mm[4], pp[4], u3[4], d3[4];
                 tile_row_quad(tile6, trow, lo, hi, c);
@@ -817,10 +822,11 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
             else {
                 sc = fast_bright_score(&tile[toff]) - 1;
             }
-            const bool corner = sc >= thr;
-            score[(r + 1) * 68 + c + 1] = (uint8_t)(corner ? sc : 0);
-            if (compact && corner) {
-                corners[atomicAdd(&ncorner, 1)] = (unsigned short)item;
+            if (sc >= thr) { // (the plane is all zero: only corners are written)
+                score[(r + 1) * 68 + c + 1] = (uint8_t)sc;
+                if (compact) {
+                    corners[atomicAdd(&ncorner, 1)] = (unsigned short)item;
+                }
             }
         }
         lds_barrier();
