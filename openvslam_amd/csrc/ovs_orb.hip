@@ -937,25 +937,18 @@ constexpr int kBlurCols = 256; // output columns per wave tile (four per lane)
 // The blur is the exact integer double sum  out = min((sum_j sum_i k[j] k[i] p[y+j][x+i] + 2^15) >> 16, 255):
 // the row pass never rounds (<= 255 * 257 = 65535), so the passes may run in either order and
 // on any grouping of taps.  One wavefront owns a tile of 256 columns x 64 rows and walks down
-// the rows with no LDS and no barrier:
-//   * row pass on raw bytes: a lane holds the four bytes of its columns (C) and gets the dwords of
-//     its left / right neighbours (L, R) by DPP wave shifts (lanes 0 and 63 load theirs); the
-//     seven-byte windows are cut with v_alignbyte and reduced with v_dot4_u32_u8 (two per pixel);
+// the rows with no LDS, no barrier and no exchange between lanes:
+//   * a lane fetches the twelve source bytes around its four columns (the dword left of its own, its
+//     own, the one right of it) with three dword loads of any alignment; the second and third hit the
+//     cache lines of the first.  BORDER_REFLECT_101 along the row is part of the fetch: every dword of
+//     the reflected row is four bytes of ONE dword of the real row in some order (see blur_ext_dword),
+//     so a lane at an image border loads from a shifted offset and reorders with one v_perm; tiles
+//     that touch no border skip the v_perm (rows are reflected in scalar code);
+//   * row pass on raw bytes: the seven taps are laid over the three dwords as they are and reduced
+//     with v_dot4_u32_u8 (ten for four pixels);
 //   * two consecutive row-pass results are packed as u16 pairs, so the column pass is four
 //     v_dot2_u32_u16 per pixel; the accumulator starts at 0xFF008000 and every dot saturates, which
-//     makes byte 2 of the result the rounded, 255-clamped output with no extra instruction;
-//   * all source bytes are fetched through per-lane offsets that already contain the
-//     BORDER_REFLECT_101 column mapping, so edges, odd strides and unaligned rows need no special
-//     path (rows are reflected in scalar code).
-__device__ __forceinline__ u32 dpp_from_left(u32 own, u32 edge) {
-    // lane i receives lane i - 1's value; lane 0 keeps `edge`
-    return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)own, 0x138, 0xf, 0xf, false); // wave_shr:1
-}
-__device__ __forceinline__ u32 dpp_from_right(u32 own, u32 edge) {
-    // lane i receives lane i + 1's value; lane 63 keeps `edge`
-    return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)own, 0x130, 0xf, 0xf, false); // wave_shl:1
-}
-
+//     makes byte 2 of the result the rounded, 255-clamped output with no extra instruction.
 __device__ __forceinline__ u32 udot2_sat(u32 a, u32 w, u32 acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, w), acc, true);
 }
@@ -970,82 +963,50 @@ __device__ __forceinline__ int reflect101_near(int p, int len) {
     return p >= len ? 2 * len - 2 - p : p;
 }
 
-// Per-lane, per-tile constants of the row pass.
-struct blur_lane {
-    u32 off[4];   // reflected byte offsets of the lane's columns (byte path)
-    u32 eoff[4];  // the same for the halo dword of lanes 0 / 63
-    u32 voff;     // 4 * lane: dword path
-    bool byte_lane; // the lane's dword touches columns >= w: reflected byte loads
-    bool edge_lane; // lane 0 or 63
-};
-
-// Loads of one source row, issued ahead of their use (the tile loop keeps the next two rows in
-// flight while it computes on the current two).
-struct blur_raw {
-    u32 a0, a1; // dword path (a1 only for unaligned planes)
-    u32 b[4];   // byte path of lanes whose dword touches columns >= w
-    u32 e[4];   // halo dword of lanes 0 / 63
-};
-
-// `row_off` = byte offset of the row from the plane base, `tile_byte` = offset of the first tile
-// column inside the row (both include the base misalignment for caller-owned images).
-template <bool UNALIGNED>
-__device__ __forceinline__ blur_raw blur_row_issue(__amdgpu_buffer_rsrc_t plane, u32 row_off, u32 tile_byte, const blur_lane& ln, bool wave_has_byte_lanes) {
-    blur_raw w;
-    const u32 row_byte = row_off + tile_byte;
-    if (UNALIGNED) {
-        // rows of a caller-owned image start at any byte: two aligned dwords and a byte shift
-        w.a0 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff, row_byte & ~3u, 0);
-        w.a1 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff + 4, row_byte & ~3u, 0);
+// The dword of the reflected row ext[] (ext[x] = row[x] for 0 <= x < w, row[-x] left of it,
+// row[2w - 2 - x] right of it) that starts at column c (a multiple of 4, -4 <= c) as a dword load at
+// byte offset `off` of the real row followed by a byte permutation `sel` (v_perm selector, both
+// sources the loaded dword):
+//   c = -4            columns 4, 3, 2, 1: the dword at offset 1 reversed
+//   c + 3 < w         the dword itself
+//   c < w <= c + 3    k = w - c columns inside, then w - 2, w - 3, ...: all of them bytes of the dword at w - 4
+//   w <= c <= w + 3   columns 2w - 2 - c downwards: the dword at 2w - 5 - c reversed
+//   beyond            never used by a stored pixel: any valid offset
+// (w >= 8; every offset lies in [0, w - 4].)
+__device__ __forceinline__ void blur_ext_dword(int c, int w, u32& off, u32& sel) {
+    constexpr u32 kIdentity = 0x03020100u, kReverse = 0x00010203u;
+    off = (u32)min(max(c, 0), w - 4);
+    sel = kIdentity;
+    if (c < 0) {
+        off = 1;
+        sel = kReverse;
     }
-    else {
-        w.a0 = __builtin_amdgcn_raw_buffer_load_b32(plane, ln.voff, row_byte, 0);
-        w.a1 = 0;
+    else if (c + 3 < w) {
     }
+    else if (c < w) {
+        const int k = w - c;
+        sel = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        w.b[k] = 0;
-        w.e[k] = 0;
-    }
-    if (wave_has_byte_lanes) {
-        if (ln.byte_lane) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                w.b[k] = __builtin_amdgcn_raw_buffer_load_b8(plane, ln.off[k], row_off, 0);
-            }
+        for (int i = 0; i < 4; ++i) {
+            sel |= (u32)(i < k ? i + 4 - k : k + 2 - i) << (8 * i);
         }
     }
-    if (ln.edge_lane) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            w.e[k] = __builtin_amdgcn_raw_buffer_load_b8(plane, ln.eoff[k], row_off, 0);
-        }
+    else if (c <= w + 3) {
+        off = (u32)(2 * w - 5 - c);
+        sel = kReverse;
     }
-    return w;
 }
 
-template <bool UNALIGNED>
-__device__ __forceinline__ blur_row blur_row_finish(const blur_raw& w, u32 shift, const blur_lane& ln, bool wave_has_byte_lanes) {
-    // kernel bytes, LSB first: taps 0..3 and taps 4..6
-    constexpr u32 kWa = 18u | (34u << 8) | (49u << 16) | (55u << 24);
-    constexpr u32 kWb = 49u | (34u << 8) | (18u << 16);
-    u32 c = UNALIGNED ? __builtin_amdgcn_alignbyte(w.a1, w.a0, shift) : w.a0;
-    if (wave_has_byte_lanes) {
-        const u32 cb = w.b[0] | (w.b[1] << 8) | (w.b[2] << 16) | (w.b[3] << 24);
-        c = ln.byte_lane ? cb : c;
-    }
-    const u32 e = w.e[0] | (w.e[1] << 8) | (w.e[2] << 16) | (w.e[3] << 24);
-    const u32 l = dpp_from_left(c, e);
-    const u32 r = dpp_from_right(c, e);
-    // The window of output column j (0..3) is bytes j + 1 .. j + 7 of the twelve bytes (l, c, r): instead of
-    // cutting it out with v_alignbyte, the taps are laid over the three dwords as they are (weights of
-    // bytes outside the window are 0), which takes 2 + 3 + 3 + 2 v_dot4 for the four columns and no shifts.
+// Row pass for the lane's four columns from the twelve bytes (l, c, r).  The window of output column
+// j (0..3) is bytes j + 1 .. j + 7 of the twelve: instead of cutting it out with v_alignbyte, the taps
+// are laid over the three dwords as they are (weights of bytes outside the window are 0), which takes
+// 2 + 3 + 3 + 2 v_dot4 for the four columns and no shifts.
+__device__ __forceinline__ blur_row blur_row_pass(u32 l, u32 c, u32 r) {
     constexpr u32 k0 = 18, k1 = 34, k2 = 49, k3 = 55;
     constexpr u32 kL0 = (k0 << 8) | (k1 << 16) | (k2 << 24), kC0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
     constexpr u32 kL1 = (k0 << 16) | (k1 << 24), kC1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), kR1 = k0;
     constexpr u32 kL2 = (k0 << 24), kC2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), kR2 = k1 | (k0 << 8);
     constexpr u32 kC3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), kR3 = k2 | (k1 << 8) | (k0 << 16);
-    static_assert(kC3 == kWa && kR3 == kWb, "column 3 is the unshifted window");
     blur_row out;
     out.h[0] = __builtin_amdgcn_udot4(c, kC0, __builtin_amdgcn_udot4(l, kL0, 0u, false), false);
     out.h[1] = __builtin_amdgcn_udot4(r, kR1, __builtin_amdgcn_udot4(c, kC1, __builtin_amdgcn_udot4(l, kL1, 0u, false), false), false);
@@ -1076,86 +1037,107 @@ __device__ __forceinline__ u32 blur_col_pass(const u32 (&q0)[4], const u32 (&q1)
     return lo | hi;
 }
 
-template <bool UNALIGNED>
-__device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* img, u32 pitch, uint8_t* dst, int y0, int cb, int lane) {
-    const int nrows = min(kBlurRows, g.h - y0);
-    // the level plane as a buffer resource based at the 4-byte aligned address at or below its
-    // first byte: loads take (per-lane byte offset, scalar row offset) and need no address
-    // arithmetic; reads outside the plane return 0 instead of faulting (the size is rounded up to
-    // whole dwords: a dword that straddles the end would read as 0, and one that holds a valid byte
-    // is always backed by memory)
-    const u32 delta = UNALIGNED ? (u32)(reinterpret_cast<uintptr_t>(img) & 3) : 0u;
-    const __amdgpu_buffer_rsrc_t plane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img) - delta, 0,
-                                                                           (int)((delta + pitch * (u32)(g.h - 1) + (u32)g.w + 3u) & ~3u), 0x00020000);
-    // column indices reflected (BORDER_REFLECT_101) and clamped to the reach of the 7-tap window
-    // beyond the last column
-    const int col = cb + 4 * lane;
-    const int ecol = lane == 0 ? cb - 4 : cb + kBlurCols;
-    blur_lane ln;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ln.off[k] = delta + (u32)reflect101_near(min(col + k, g.w + 2), g.w);
-        ln.eoff[k] = delta + (u32)reflect101_near(min(ecol + k, g.w + 2), g.w);
-    }
-    ln.voff = 4u * (u32)lane;
-    ln.byte_lane = col + 4 > g.w;
-    ln.edge_lane = lane == 0 || lane == 63;
-    const bool wave_has_byte_lanes = cb + kBlurCols > g.w;
-    const bool store_lane = col < g.pitch;
-    const u32 tile_byte = delta + (u32)cb;
+// The three dwords of one source row, loaded ahead of their use.
+struct blur_raw {
+    u32 l, c, r;
+};
 
+// Per-lane, per-tile constants of the row fetch; BORDER: the tile touches the first or the last column
+// of the image, its lanes reorder what they load.
+template <bool BORDER>
+struct blur_src {
+    const uint8_t* img;
+    u32 pitch;
+    u32 off_l, off_c, off_r;
+    u32 sel_l, sel_c, sel_r;
+    __device__ __forceinline__ blur_raw issue(int row) const {
+        const uint8_t* rp = img + (size_t)((u32)row * pitch);
+        // (the offsets pass through an empty asm so that their zero extension stays next to the loads and
+        // the loads take the scalar-base + 32-bit-offset form instead of per-lane 64-bit addresses)
+        u32 ol = off_l, oc = off_c, orr = off_r;
+        asm volatile("" : "+v"(ol), "+v"(oc), "+v"(orr));
+        blur_raw w;
+        w.c = *reinterpret_cast<const u32_unaligned*>(rp + oc);
+        w.l = *reinterpret_cast<const u32_unaligned*>(rp + ol);
+        w.r = *reinterpret_cast<const u32_unaligned*>(rp + orr);
+        return w;
+    }
+    __device__ __forceinline__ blur_row finish(const blur_raw& w) const {
+        if (BORDER) {
+            return blur_row_pass(__builtin_amdgcn_perm(w.l, w.l, sel_l), __builtin_amdgcn_perm(w.c, w.c, sel_c), __builtin_amdgcn_perm(w.r, w.r, sel_r));
+        }
+        return blur_row_pass(w.l, w.c, w.r);
+    }
+};
+
+// The row loop of a wave tile: walks down the tile's source rows two at a time (the loads of the next
+// pair in flight while the current pair is reduced) and emits two output rows per step.  Row pair t
+// of the tile is image rows y0 - 3 + 2t, y0 - 2 + 2t; output rows 2i, 2i + 1 need pairs i .. i + 3.
+template <typename Src>
+__device__ __forceinline__ void blur_tile_rows(const level_geom& g, const Src& src, uint8_t* dst, int y0, int col, bool store_lane) {
+    const int nrows = min(kBlurRows, g.h - y0);
+    const int last = g.h + 2; // rows past the image that the last output row reaches: clamp, then reflect
+    auto row_of = [&](int t, int k) { return reflect101_near(min(y0 - 3 + 2 * t + k, last), g.h); };
     u32 q[4][4];
-    // input row j of the tile is image row y0 - 3 + j; pairs (2m, 2m + 1)
-    u32 ra = (u32)reflect101_near(y0 - 3, g.h) * pitch, rb = (u32)reflect101_near(y0 - 2, g.h) * pitch;
-    blur_raw wa = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
-    blur_raw wb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
-#pragma unroll
-    for (int m = 0; m < 3; ++m) {
-        const u32 sa = (ra + tile_byte) & 3u, sb = (rb + tile_byte) & 3u;
-        ra = (u32)reflect101_near(y0 - 1 + 2 * m, g.h) * pitch;
-        rb = (u32)reflect101_near(y0 + 2 * m, g.h) * pitch;
-        const blur_raw na = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
-        const blur_raw nb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
-        const blur_row a = blur_row_finish<UNALIGNED>(wa, sa, ln, wave_has_byte_lanes);
-        const blur_row b = blur_row_finish<UNALIGNED>(wb, sb, ln, wave_has_byte_lanes);
+    blur_raw pa = src.issue(row_of(0, 0)), pb = src.issue(row_of(0, 1));
+    auto step = [&](int t, int qi) { // starts pair t + 1, reduces pair t into q[qi] (qi = t & 3, a constant after unrolling)
+        const blur_raw na = src.issue(row_of(t + 1, 0));
+        const blur_raw nb = src.issue(row_of(t + 1, 1));
+        const blur_row a = src.finish(pa);
+        const blur_row b = src.finish(pb);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            q[m][c] = a.h[c] | (b.h[c] << 16);
+            q[qi][c] = a.h[c] | (b.h[c] << 16);
         }
-        wa = na;
-        wb = nb;
+        pa = na;
+        pb = nb;
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        step(t, t);
     }
-    // here wa / wb hold rows y0 + 3, y0 + 4: the pair the first two output rows still need
 #pragma unroll 1
     for (int o = 0; o < nrows; o += 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int oo = o + 2 * i; // output rows oo, oo + 1 need pairs oo/2 .. oo/2 + 3
+            const int oo = o + 2 * i; // output rows oo, oo + 1: pairs i .. i + 3 (mod 4: the loop advances by four pairs)
             if (oo < nrows) {
-                const u32 sa = (ra + tile_byte) & 3u, sb = (rb + tile_byte) & 3u;
-                // rows of the next step (reflected, so always inside the plane)
-                ra = (u32)reflect101_near(min(y0 + oo + 5, g.h + 2), g.h) * pitch;
-                rb = (u32)reflect101_near(min(y0 + oo + 6, g.h + 2), g.h) * pitch;
-                const blur_raw na = blur_row_issue<UNALIGNED>(plane, ra, tile_byte, ln, wave_has_byte_lanes);
-                const blur_raw nb = blur_row_issue<UNALIGNED>(plane, rb, tile_byte, ln, wave_has_byte_lanes);
-                const blur_row a = blur_row_finish<UNALIGNED>(wa, sa, ln, wave_has_byte_lanes);
-                const blur_row b = blur_row_finish<UNALIGNED>(wb, sb, ln, wave_has_byte_lanes);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    q[(i + 3) & 3][c] = a.h[c] | (b.h[c] << 16);
-                }
+                step((o >> 1) + i + 3, (i + 3) & 3);
                 const u32 r0 = blur_col_pass<false>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
                 const u32 r1 = blur_col_pass<true>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
                 if (store_lane) {
-                    *reinterpret_cast<u32*>(dst + (long long)oo * g.pitch + col) = r0;
+                    u32 oc = (u32)col;
+                    asm volatile("" : "+v"(oc)); // scalar row base + 32-bit lane offset, as for the loads
+                    uint8_t* drow = dst + (size_t)((u32)oo * (u32)g.pitch);
+                    *reinterpret_cast<u32*>(drow + oc) = r0;
                     if (oo + 1 < nrows) {
-                        *reinterpret_cast<u32*>(dst + (long long)(oo + 1) * g.pitch + col) = r1;
+                        uint8_t* drow1 = dst + (size_t)((u32)(oo + 1) * (u32)g.pitch);
+                        u32 oc1 = (u32)col;
+                        asm volatile("" : "+v"(oc1));
+                        *reinterpret_cast<u32*>(drow1 + oc1) = r1;
                     }
                 }
-                wa = na;
-                wb = nb;
             }
         }
+    }
+}
+
+__device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* img, u32 pitch, uint8_t* dst, int y0, int cb, int lane) {
+    const int col = cb + 4 * lane;
+    const bool store_lane = col < g.pitch;
+    if (cb > 0 && cb + kBlurCols + 4 <= g.w) {
+        // every source dword of the tile lies inside its image row
+        const blur_src<false> src{img, pitch, (u32)col - 4u, (u32)col, (u32)col + 4u, 0u, 0u, 0u};
+        blur_tile_rows(g, src, dst, y0, col, store_lane);
+    }
+    else {
+        blur_src<true> src;
+        src.img = img;
+        src.pitch = pitch;
+        blur_ext_dword(col - 4, g.w, src.off_l, src.sel_l);
+        blur_ext_dword(col, g.w, src.off_c, src.sel_c);
+        blur_ext_dword(col + 4, g.w, src.off_r, src.sel_r);
+        blur_tile_rows(g, src, dst, y0, col, store_lane);
     }
 }
 
@@ -1185,14 +1167,9 @@ __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t
     long long pitch64;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch64);
     uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)y0 * g.pitch;
-    // library planes are 256-byte aligned with a pitch that is a multiple of 64; a caller's
-    // level-0 image may start anywhere and have any stride
-    if (level == 0 && (((reinterpret_cast<uintptr_t>(img) | (uintptr_t)pitch64) & 3) != 0)) {
-        blur_tile<true>(g, img, (u32)pitch64, dst, y0, cb, lane);
-    }
-    else {
-        blur_tile<false>(g, img, (u32)pitch64, dst, y0, cb, lane);
-    }
+    // (library planes are 256-byte aligned with a pitch that is a multiple of 64; a caller's level-0 image
+    // may start anywhere and have any stride: the row fetch takes any alignment)
+    blur_tile(g, img, (u32)pitch64, dst, y0, cb, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1769,8 +1746,14 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
 //   pattern; util::cos / util::sin (util/trigonometric.h:17-46) and the rotated coordinates are
 //   evaluated in the reference's operation order in fp32, cvRound = round-half-even.
 // -------------------------------------------------------------------------------------------------
-__constant__ int8_t c_pattern[1024];
-__constant__ int c_umax[16];
+// Tables of the descriptor kernel, built on the host (upload_constants) in the layout the kernel keeps
+// in LDS, so that a workgroup stages them with one 16-byte load per thread:
+//   g_pat[17 g + k]               (x0, y0, x1, y1) of sample pair 16 g + k as fp32 (padded so that the 16 lanes
+//                                 of a keypoint's group hit distinct banks)
+//   g_disc_mask[(av * 4 + mis) * 3 + part]   byte masks of the three dwords of a 12-byte part of the disc row
+//                                 |v| = av (16 = empty) whose first byte lies `mis` bytes left of u = -16
+__device__ float4 g_pat[16 * 17];
+__device__ uint4 g_disc_mask[17 * 4 * 3];
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     const float scale = (float)(180.0 / 3.14159265358979323846);
@@ -1913,24 +1896,12 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     }
     {
         const int t = threadIdx.x;
-        const int8_t* pp = &c_pattern[t * 4];
-        pat[(t >> 4) * 17 + (t & 15)] = make_float4((float)pp[0], (float)pp[1], (float)pp[2], (float)pp[3]);
+        pat[t] = g_pat[t];
+        if (t < 16 * 17 - 256) {
+            pat[256 + t] = g_pat[256 + t];
+        }
         if (t < 17 * 4 * 3) {
-            // window byte wb = 12 part + 4 d + b of a row whose first byte lies `mis` bytes left of
-            // u = -16 has u = wb - 16 - mis
-            const int av = t / 12, mis = (t - 12 * av) / 3, part = t - 12 * av - 3 * mis;
-            const int dmax = av <= kHalfPatch ? c_umax[av] : -1;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                u32 m = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const int u = 12 * part + 4 * d + b - 16 - mis;
-                    m |= ((u < 0 ? -u : u) <= dmax) ? (0xFFu << (8 * b)) : 0u;
-                }
-                disc_mask[av][mis][part][d] = m;
-            }
-            disc_mask[av][mis][part][3] = 0;
+            reinterpret_cast<uint4*>(&disc_mask[0][0][0][0])[t] = g_disc_mask[t];
         }
     }
     __syncthreads();
@@ -2430,8 +2401,32 @@ int upload_constants(ovs_orb* h) {
     if (h->constants_uploaded) {
         return OVS_OK;
     }
-    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), ovs_orb_pattern, 1024));
-    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_umax), h->u_max, sizeof(int) * 16));
+    std::vector<float> pat(4 * 16 * 17, 0.f);
+    for (int t = 0; t < 256; ++t) {
+        for (int k = 0; k < 4; ++k) {
+            pat[4 * ((t >> 4) * 17 + (t & 15)) + k] = static_cast<float>(ovs_orb_pattern[4 * t + k]);
+        }
+    }
+    std::vector<uint32_t> masks(4 * 17 * 4 * 3, 0u);
+    for (int av = 0; av < 17; ++av) {
+        const int dmax = av <= kHalfPatch ? h->u_max[av] : -1;
+        for (int mis = 0; mis < 4; ++mis) {
+            for (int part = 0; part < 3; ++part) {
+                for (int d = 0; d < 3; ++d) {
+                    // window byte wb = 12 part + 4 d + b of a row whose first byte lies `mis` bytes left
+                    // of u = -16 has u = wb - 16 - mis
+                    uint32_t m = 0;
+                    for (int b = 0; b < 4; ++b) {
+                        const int u = 12 * part + 4 * d + b - 16 - mis;
+                        m |= (std::abs(u) <= dmax) ? (0xFFu << (8 * b)) : 0u;
+                    }
+                    masks[4 * ((av * 4 + mis) * 3 + part) + d] = m;
+                }
+            }
+        }
+    }
+    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pat), pat.data(), pat.size() * sizeof(float)));
+    OVS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_disc_mask), masks.data(), masks.size() * sizeof(uint32_t)));
     h->constants_uploaded = true;
     return OVS_OK;
 }

@@ -27,6 +27,34 @@ __global__ void k(unsigned* out, int iters, unsigned long long* cyc) {
         if (OP == 11) { REP16(asm volatile("v_add_u32_dpp %0, %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %1, %1, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %2, %2, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %3, %3, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n v_add_u32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
         if (OP == 12) { REP16(asm volatile("v_min_u16_e32 %0, %8, %0\n v_min_u16_e32 %1, %8, %1\n v_min_u16_e32 %2, %8, %2\n v_min_u16_e32 %3, %8, %3\n v_min_u16_e32 %4, %8, %4\n v_min_u16_e32 %5, %8, %5\n v_min_u16_e32 %6, %8, %6\n v_min_u16_e32 %7, %8, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
         if (OP == 13) { REP16(asm volatile("v_lshrrev_b32_e32 %0, 8, %0\n v_lshrrev_b32_e32 %1, 8, %1\n v_lshrrev_b32_e32 %2, 8, %2\n v_lshrrev_b32_e32 %3, 8, %3\n v_lshrrev_b32_e32 %4, 8, %4\n v_lshrrev_b32_e32 %5, 8, %5\n v_lshrrev_b32_e32 %6, 8, %6\n v_lshrrev_b32_e32 %7, 8, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 14) { REP16(asm volatile("v_and_or_b32 %0, %0, %8, %9\n v_and_or_b32 %1, %1, %8, %9\n v_and_or_b32 %2, %2, %8, %9\n v_and_or_b32 %3, %3, %8, %9\n v_and_or_b32 %4, %4, %8, %9\n v_and_or_b32 %5, %5, %8, %9\n v_and_or_b32 %6, %6, %8, %9\n v_and_or_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 15) { REP16(asm volatile("v_bfi_b32 %0, %0, %8, %9\n v_bfi_b32 %1, %1, %8, %9\n v_bfi_b32 %2, %2, %8, %9\n v_bfi_b32 %3, %3, %8, %9\n v_bfi_b32 %4, %4, %8, %9\n v_bfi_b32 %5, %5, %8, %9\n v_bfi_b32 %6, %6, %8, %9\n v_bfi_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 16) { REP16(asm volatile("v_or3_b32 %0, %0, %8, %9\n v_or3_b32 %1, %1, %8, %9\n v_or3_b32 %2, %2, %8, %9\n v_or3_b32 %3, %3, %8, %9\n v_or3_b32 %4, %4, %8, %9\n v_or3_b32 %5, %5, %8, %9\n v_or3_b32 %6, %6, %8, %9\n v_or3_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 17) { REP16(asm volatile("v_lshl_or_b32 %0, %0, %8, %9\n v_lshl_or_b32 %1, %1, %8, %9\n v_lshl_or_b32 %2, %2, %8, %9\n v_lshl_or_b32 %3, %3, %8, %9\n v_lshl_or_b32 %4, %4, %8, %9\n v_lshl_or_b32 %5, %5, %8, %9\n v_lshl_or_b32 %6, %6, %8, %9\n v_lshl_or_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 18) { REP16(asm volatile("v_add3_u32 %0, %0, %8, %9\n v_add3_u32 %1, %1, %8, %9\n v_add3_u32 %2, %2, %8, %9\n v_add3_u32 %3, %3, %8, %9\n v_add3_u32 %4, %4, %8, %9\n v_add3_u32 %5, %5, %8, %9\n v_add3_u32 %6, %6, %8, %9\n v_add3_u32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 19) { REP16(asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 20) { REP16(asm volatile("v_alignbyte_b32 %0, %0, %8, %9\n v_alignbyte_b32 %1, %1, %8, %9\n v_alignbyte_b32 %2, %2, %8, %9\n v_alignbyte_b32 %3, %3, %8, %9\n v_alignbyte_b32 %4, %4, %8, %9\n v_alignbyte_b32 %5, %5, %8, %9\n v_alignbyte_b32 %6, %6, %8, %9\n v_alignbyte_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 21) { REP16(asm volatile("v_alignbit_b32 %0, %0, %8, %9\n v_alignbit_b32 %1, %1, %8, %9\n v_alignbit_b32 %2, %2, %8, %9\n v_alignbit_b32 %3, %3, %8, %9\n v_alignbit_b32 %4, %4, %8, %9\n v_alignbit_b32 %5, %5, %8, %9\n v_alignbit_b32 %6, %6, %8, %9\n v_alignbit_b32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 22) { REP16(asm volatile("v_bfe_u32 %0, %0, %8, %9\n v_bfe_u32 %1, %1, %8, %9\n v_bfe_u32 %2, %2, %8, %9\n v_bfe_u32 %3, %3, %8, %9\n v_bfe_u32 %4, %4, %8, %9\n v_bfe_u32 %5, %5, %8, %9\n v_bfe_u32 %6, %6, %8, %9\n v_bfe_u32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 23) { REP16(asm volatile("v_lshl_add_u32 %0, %0, %8, %9\n v_lshl_add_u32 %1, %1, %8, %9\n v_lshl_add_u32 %2, %2, %8, %9\n v_lshl_add_u32 %3, %3, %8, %9\n v_lshl_add_u32 %4, %4, %8, %9\n v_lshl_add_u32 %5, %5, %8, %9\n v_lshl_add_u32 %6, %6, %8, %9\n v_lshl_add_u32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 24) { REP16(asm volatile("v_sad_u8 %0, %0, %8, %9\n v_sad_u8 %1, %1, %8, %9\n v_sad_u8 %2, %2, %8, %9\n v_sad_u8 %3, %3, %8, %9\n v_sad_u8 %4, %4, %8, %9\n v_sad_u8 %5, %5, %8, %9\n v_sad_u8 %6, %6, %8, %9\n v_sad_u8 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 25) { REP16(asm volatile("v_xad_u32 %0, %0, %8, %9\n v_xad_u32 %1, %1, %8, %9\n v_xad_u32 %2, %2, %8, %9\n v_xad_u32 %3, %3, %8, %9\n v_xad_u32 %4, %4, %8, %9\n v_xad_u32 %5, %5, %8, %9\n v_xad_u32 %6, %6, %8, %9\n v_xad_u32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 26) { REP16(asm volatile("v_med3_u32 %0, %0, %8, %9\n v_med3_u32 %1, %1, %8, %9\n v_med3_u32 %2, %2, %8, %9\n v_med3_u32 %3, %3, %8, %9\n v_med3_u32 %4, %4, %8, %9\n v_med3_u32 %5, %5, %8, %9\n v_med3_u32 %6, %6, %8, %9\n v_med3_u32 %7, %7, %8, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 27) { REP16(asm volatile("v_sub_u32 %0, %0, %8\n v_sub_u32 %1, %1, %8\n v_sub_u32 %2, %2, %8\n v_sub_u32 %3, %3, %8\n v_sub_u32 %4, %4, %8\n v_sub_u32 %5, %5, %8\n v_sub_u32 %6, %6, %8\n v_sub_u32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 28) { REP16(asm volatile("v_or_b32 %0, %0, %8\n v_or_b32 %1, %1, %8\n v_or_b32 %2, %2, %8\n v_or_b32 %3, %3, %8\n v_or_b32 %4, %4, %8\n v_or_b32 %5, %5, %8\n v_or_b32 %6, %6, %8\n v_or_b32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 29) { REP16(asm volatile("v_xor_b32 %0, %0, %8\n v_xor_b32 %1, %1, %8\n v_xor_b32 %2, %2, %8\n v_xor_b32 %3, %3, %8\n v_xor_b32 %4, %4, %8\n v_xor_b32 %5, %5, %8\n v_xor_b32 %6, %6, %8\n v_xor_b32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 30) { REP16(asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 31) { REP16(asm volatile("v_bcnt_u32_b32 %0, %0, %8\n v_bcnt_u32_b32 %1, %1, %8\n v_bcnt_u32_b32 %2, %2, %8\n v_bcnt_u32_b32 %3, %3, %8\n v_bcnt_u32_b32 %4, %4, %8\n v_bcnt_u32_b32 %5, %5, %8\n v_bcnt_u32_b32 %6, %6, %8\n v_bcnt_u32_b32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 32) { REP16(asm volatile("v_pk_add_u16 %0, %0, %8\n v_pk_add_u16 %1, %1, %8\n v_pk_add_u16 %2, %2, %8\n v_pk_add_u16 %3, %3, %8\n v_pk_add_u16 %4, %4, %8\n v_pk_add_u16 %5, %5, %8\n v_pk_add_u16 %6, %6, %8\n v_pk_add_u16 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 33) { REP16(asm volatile("v_pk_mul_lo_u16 %0, %0, %8\n v_pk_mul_lo_u16 %1, %1, %8\n v_pk_mul_lo_u16 %2, %2, %8\n v_pk_mul_lo_u16 %3, %3, %8\n v_pk_mul_lo_u16 %4, %4, %8\n v_pk_mul_lo_u16 %5, %5, %8\n v_pk_mul_lo_u16 %6, %6, %8\n v_pk_mul_lo_u16 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 34) { REP16(asm volatile("v_lshlrev_b32 %0, %0, %8\n v_lshlrev_b32 %1, %1, %8\n v_lshlrev_b32 %2, %2, %8\n v_lshlrev_b32 %3, %3, %8\n v_lshlrev_b32 %4, %4, %8\n v_lshlrev_b32 %5, %5, %8\n v_lshlrev_b32 %6, %6, %8\n v_lshlrev_b32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 35) { REP16(asm volatile("v_min_u32 %0, %0, %8\n v_min_u32 %1, %1, %8\n v_min_u32 %2, %2, %8\n v_min_u32 %3, %3, %8\n v_min_u32 %4, %4, %8\n v_min_u32 %5, %5, %8\n v_min_u32 %6, %6, %8\n v_min_u32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 36) { REP16(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 37) { REP16(asm volatile("v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3\n v_ffbl_b32 %4, %4\n v_ffbl_b32 %5, %5\n v_ffbl_b32 %6, %6\n v_ffbl_b32 %7, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 38) { REP16(asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %1, %1\n v_mov_b32 %2, %2\n v_mov_b32 %3, %3\n v_mov_b32 %4, %4\n v_mov_b32 %5, %5\n v_mov_b32 %6, %6\n v_mov_b32 %7, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 39) { REP16(asm volatile("v_not_b32 %0, %0\n v_not_b32 %1, %1\n v_not_b32 %2, %2\n v_not_b32 %3, %3\n v_not_b32 %4, %4\n v_not_b32 %5, %5\n v_not_b32 %6, %6\n v_not_b32 %7, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 40) { REP16(asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 41) { REP16(asm volatile("v_dot2_u32_u16 %0, %8, %9, %0\n v_dot2_u32_u16 %1, %8, %9, %1\n v_dot2_u32_u16 %2, %8, %9, %2\n v_dot2_u32_u16 %3, %8, %9, %3\n v_dot2_u32_u16 %4, %8, %9, %4\n v_dot2_u32_u16 %5, %8, %9, %5\n v_dot2_u32_u16 %6, %8, %9, %6\n v_dot2_u32_u16 %7, %8, %9, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
@@ -85,5 +113,33 @@ int main() {
     run<11>("v_add_u32_dpp");
     run<12>("v_min_u16_e32");
     run<13>("v_lshrrev_e32");
+    run<14>("v_and_or_b32");
+    run<15>("v_bfi_b32");
+    run<16>("v_or3_b32");
+    run<17>("v_lshl_or_b32");
+    run<18>("v_add3_u32");
+    run<19>("v_mad_u32_u24");
+    run<20>("v_alignbyte_b32");
+    run<21>("v_alignbit_b32");
+    run<22>("v_bfe_u32");
+    run<23>("v_lshl_add_u32");
+    run<24>("v_sad_u8");
+    run<25>("v_xad_u32");
+    run<26>("v_med3_u32");
+    run<27>("v_sub_u32");
+    run<28>("v_or_b32");
+    run<29>("v_xor_b32");
+    run<30>("v_mul_u32_u24");
+    run<31>("v_bcnt_u32_b32");
+    run<32>("v_pk_add_u16");
+    run<33>("v_pk_mul_lo_u16");
+    run<34>("v_lshlrev_b32");
+    run<35>("v_min_u32");
+    run<36>("v_cndmask_b32");
+    run<37>("v_ffbl_b32");
+    run<38>("v_mov_b32");
+    run<39>("v_not_b32");
+    run<40>("v_mov_dpp_wave_shr");
+    run<41>("v_dot2_u32_u16");
     return 0;
 }
