@@ -232,7 +232,10 @@ __global__ __launch_bounds__(256) void k_resize_linear(plan_dev p, image_src s, 
 // Used when the tables are monotone with 1 <= sy(dy + 1) - sy(dy) <= 2 and every group of four
 // output columns reads at most 8 consecutive source bytes (any scale factor in (1, 2)); other
 // geometries take k_resize_linear.
-constexpr int kResizeRows = 16;
+#ifndef OVS_RESIZE_ROWS
+#define OVS_RESIZE_ROWS 16
+#endif
+constexpr int kResizeRows = OVS_RESIZE_ROWS;
 
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
@@ -931,7 +934,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
 // k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact integer row pass, column pass
 // (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).
 // -------------------------------------------------------------------------------------------------
-constexpr int kBlurRows = 64;  // output rows per wave tile
+#ifndef OVS_BLUR_ROWS
+#define OVS_BLUR_ROWS 64
+#endif
+constexpr int kBlurRows = OVS_BLUR_ROWS;  // output rows per wave tile
 constexpr int kBlurCols = 256; // output columns per wave tile (four per lane)
 
 // The blur is the exact integer double sum  out = min((sum_j sum_i k[j] k[i] p[y+j][x+i] + 2^15) >> 16, 255):

@@ -50,6 +50,25 @@ def test_extract_low_texture_uses_min_threshold():
     _compare(img, max_num_keypts=1000)
 
 
+@pytest.mark.parametrize("w", [253, 254, 255, 256, 257, 259, 260, 261, 262, 263, 511, 514, 517, 520, 771])
+def test_blur_borders_every_width_class(w):
+    # the blur's tiles are 256 columns wide: widths around the tile boundaries put the right image
+    # border at every byte position of a lane's dwords (reflected columns inside the lane's own dword,
+    # in its right neighbour, in the first dword of the next tile), with one, two and three column tiles;
+    # level widths w / 1.2^k add further residues, and odd widths put the rows of the uploaded image at
+    # odd addresses.  Noise: every pixel differs from its neighbours.
+    rng = np.random.default_rng(w)
+    img = rng.integers(0, 256, (97, w), dtype=np.uint8)
+    ref = oracle.OrbExtractor(max_num_keypts=300, num_levels=3)
+    ref.extract(img, None)
+    ext = orb_extractor(orb_params(max_num_keypts=300, num_levels=3))
+    ext.extract(img, None)
+    for lvl in range(3):
+        rb = ref.blurred_level(lvl)
+        assert rb is not None
+        assert np.array_equal(ext.blurred_level(lvl), rb), "blurred level %d differs at width %d" % (lvl, w)
+
+
 @pytest.mark.parametrize("kind", ["uniform", "salt_pepper", "checker"])
 def test_extract_dense_corner_images(kind):
     # images in which most pixels pass the FAST rejection test: the per-cell survivor list runs
