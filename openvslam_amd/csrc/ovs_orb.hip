@@ -1885,12 +1885,21 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     const int gl = threadIdx.x & (kKpGroup - 1);
     const int grp = threadIdx.x / kKpGroup;
     // Output slot oi of the frame (level-major concatenation, orb_extractor.cc:120-143) is keypoint
-    // oi - before(level) of the level whose running count first exceeds oi.  Per-level counts:
-    // one lane per level (num_levels <= 16 = group width), inclusive scan over the group.
-    const int myc = gl < p.num_levels ? lvl_count[frame * p.num_levels + gl] : 0;
-    const int bad = row16_sum_i32(myc < 0 ? 1 : 0);
-    const int incl = row16_incl_scan_i32(max(myc, 0));
-    const int total = row16_sum_i32(max(myc, 0));
+    // oi - before(level) of the level whose running count first exceeds oi.  The per-level counts of
+    // the frame are the same for every thread of the workgroup: scalar loads (every workgroup of the
+    // frame reads the same few dwords, so all but the first hit the scalar cache) and scalar sums; a
+    // workgroup past the frame's last keypoint leaves before it has issued a vector instruction.
+    const int* __restrict__ cnt = lvl_count + frame * p.num_levels;
+    int incl_l[16];
+    int total = 0, bad = 0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        const int cl = cnt[l]; // (the array ends with 16 spare entries: every load is in bounds, no branch between them)
+        const int c = l < p.num_levels ? cl : 0;
+        bad |= c < 0 ? 1 : 0;
+        total += max(c, 0);
+        incl_l[l] = total;
+    }
     const int oi = fblk * (256 / kKpGroup) + grp;
     if (oi == 0 && gl == 0) {
         // a negative count flags a truncated frame (capacity) or an internal overflow (INT_MIN)
@@ -1914,10 +1923,15 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     if (oi >= n_out) {
         return;
     }
-    // level = number of levels whose inclusive count is <= oi
-    const u64 le = __ballot(gl < p.num_levels && incl <= oi);
-    const int level = __popc((u32)(le >> (16 * (threadIdx.x >> 4 & 3))) & 0xFFFFu);
-    const int before = row16_sum_i32(gl < level ? max(myc, 0) : 0); // keypoints of the lower levels
+    // level = number of levels whose inclusive count is <= oi; before = the count of the lower levels
+    int level = 0, before = 0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+        if (l < p.num_levels && incl_l[l] <= oi) {
+            level = l + 1;
+            before = incl_l[l];
+        }
+    }
     const level_geom& g = p.lv[level];
     const int j = g.kp_base + (oi - before); // slot in the per-frame level-keypoint arrays
 
@@ -1933,7 +1947,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     const __amdgpu_buffer_rsrc_t bplane = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(blur) + frame * p.frame_blur_bytes, 0,
                                                                             (int)p.frame_blur_bytes, 0x00020000);
     const int step = g.pitch;
-    const int first = (int)g.blur_off + (py - kPatchR) * step + px - kPatchR; // byte (-18, -18)
+    const int first = (int)g.blur_off + __mul24(py - kPatchR, step) + px - kPatchR; // byte (-18, -18)
     const int first_al = first & ~3, sh = first & 3;
     u32* my_patch = reinterpret_cast<u32*>(&patch[grp][0]);
     // A row is three 16-byte parts, a part is one lane's buffer_load_dwordx4 (the texture path
@@ -1954,29 +1968,35 @@ __global__ __launch_bounds__(256) void k_orient_desc(plan_dev p, image_src s, co
     // A disc row is the 31 bytes u = -15 .. 15; from the dword boundary at or below u = -16 that is
     // at most 36 bytes = three 12-byte parts, each one lane's 12-byte load: 93 parts in six loads
     // of the group's 16 lanes (the three spare slots read row 16 through an empty mask).
+    // (All products here have small factors: 24-bit multiplies.  A 32-bit or 64-bit integer multiply
+    // takes four times as long to issue, and the row address of every part used to be one.)
     long long pitch;
     const uint8_t* img = level_ptr(p, s, frame, level, pitch);
     typedef u32 u32x3_a4 __attribute__((ext_vector_type(3), aligned(4)));
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-    const uint8_t* win = img + (long long)py * pitch + (px - 16); // (v, u) = (0, -16)
+    const int pitch32 = (int)pitch; // a level plane is far smaller than 2^31 bytes
+    const uint8_t* win = img + (__mul24(py, pitch32) + (px - 16)); // (v, u) = (0, -16)
+    const u32 win_lo = (u32)reinterpret_cast<uintptr_t>(win);
+    const uint4* masks = reinterpret_cast<const uint4*>(&disc_mask[0][0][0][0]);
     int m10 = 0, m01 = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        const int slot = 16 * k + gl;
-        const int ri = (slot * 171) >> 9; // slot / 3
-        const int part = slot - 3 * ri;
-        const int v = ri - kHalfPatch;    // 16 in the spare slots
-        const int av = v < 0 ? -v : v;
-        const uint8_t* rowp = win + (long long)v * pitch;
-        const u32 mis = (u32)reinterpret_cast<uintptr_t>(rowp) & 3u;
-        const u32x3_a4 w = *reinterpret_cast<const u32x3_a4*>(rowp - mis + 12 * part);
-        const u32x4 mk = *reinterpret_cast<const u32x4*>(&disc_mask[av][mis][part][0]);
+        const u32 slot = 16u * k + (u32)gl;
+        const u32 ri = __umul24(slot, 171u) >> 9; // slot / 3
+        const u32 part = slot - __umul24(ri, 3u);
+        const int v = (int)ri - kHalfPatch;       // 16 in the spare slots
+        const u32 av = (u32)(v < 0 ? -v : v);
+        const int off = __mul24(v, pitch32);      // row v relative to the window row
+        const u32 mis = (win_lo + (u32)off) & 3u; // misalignment of the row's byte u = -16
+        const int part12 = (int)__umul24(part, 12u);
+        const u32x3_a4 w = *reinterpret_cast<const u32x3_a4*>(win + (off - (int)mis + part12));
+        const uint4 mk = masks[__umul24(av, 12u) + __umul24(mis, 3u) + part];
         const u32 w0 = w.x & mk.x, w1 = w.y & mk.y, w2 = w.z & mk.z;
-        const u32 wt0 = 0x03020100u + 0x04040404u * (u32)(3 * part); // window byte index of the part's bytes
+        // sum of the part's bytes and sum of (byte index inside the part) * byte
         const int s0 = (int)__builtin_amdgcn_udot4(w0, 0x01010101u, __builtin_amdgcn_udot4(w1, 0x01010101u, __builtin_amdgcn_udot4(w2, 0x01010101u, 0u, false), false), false);
-        const int s1 = (int)__builtin_amdgcn_udot4(w0, wt0, __builtin_amdgcn_udot4(w1, wt0 + 0x04040404u, __builtin_amdgcn_udot4(w2, wt0 + 0x08080808u, 0u, false), false), false);
-        m10 += s1 - (16 + (int)mis) * s0; // u = window byte index - 16 - mis
-        m01 += v * s0;
+        const int s1 = (int)__builtin_amdgcn_udot4(w0, 0x03020100u, __builtin_amdgcn_udot4(w1, 0x07060504u, __builtin_amdgcn_udot4(w2, 0x0B0A0908u, 0u, false), false), false);
+        m10 += s1 + __mul24(part12 - 16 - (int)mis, s0); // u = 12 part + byte index - 16 - mis
+        m01 += __mul24(v, s0);
     }
     m10 = row16_sum_i32(m10);
     m01 = row16_sum_i32(m01);
@@ -2365,7 +2385,7 @@ int ensure_buffers(ovs_orb* h, int n_frames) {
     if ((rc = h->cand.reserve(B * p.frame_cand_cap * sizeof(uint2))) != OVS_OK) return rc;
     if ((rc = h->lvl_xy.reserve(B * p.kp_total_cap * sizeof(u32))) != OVS_OK) return rc;
     if ((rc = h->lvl_resp.reserve(B * p.kp_total_cap)) != OVS_OK) return rc;
-    if ((rc = h->lvl_count.reserve(B * p.num_levels * sizeof(int))) != OVS_OK) return rc;
+    if ((rc = h->lvl_count.reserve((B * p.num_levels + 16) * sizeof(int))) != OVS_OK) return rc; // + 16: k_orient_desc reads 16 entries from a frame's first
     h->batch_cap = n_frames;
     return OVS_OK;
 }
