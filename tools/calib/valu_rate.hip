@@ -55,6 +55,14 @@ __global__ void k(unsigned* out, int iters, unsigned long long* cyc) {
         if (OP == 39) { REP16(asm volatile("v_not_b32 %0, %0\n v_not_b32 %1, %1\n v_not_b32 %2, %2\n v_not_b32 %3, %3\n v_not_b32 %4, %4\n v_not_b32 %5, %5\n v_not_b32 %6, %6\n v_not_b32 %7, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
         if (OP == 40) { REP16(asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
         if (OP == 41) { REP16(asm volatile("v_dot2_u32_u16 %0, %8, %9, %0\n v_dot2_u32_u16 %1, %8, %9, %1\n v_dot2_u32_u16 %2, %8, %9, %2\n v_dot2_u32_u16 %3, %8, %9, %3\n v_dot2_u32_u16 %4, %8, %9, %4\n v_dot2_u32_u16 %5, %8, %9, %5\n v_dot2_u32_u16 %6, %8, %9, %6\n v_dot2_u32_u16 %7, %8, %9, %7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 42) { REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]\n v_cndmask_b32_e64 %4, %4, %8, s[20:21]\n v_cndmask_b32_e64 %5, %5, %8, s[20:21]\n v_cndmask_b32_e64 %6, %6, %8, s[20:21]\n v_cndmask_b32_e64 %7, %7, %8, s[20:21]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "s20", "s21");) }
+        if (OP == 43) { asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc"); REP16(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 44) { REP16(asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %8\n v_add_u32 %0, %0, %9\n v_cmp_lt_u32_e64 s[20:21], %1, %8\n v_add_u32 %1, %1, %9\n v_cmp_lt_u32_e64 s[20:21], %2, %8\n v_add_u32 %2, %2, %9\n v_cmp_lt_u32_e64 s[20:21], %3, %8\n v_add_u32 %3, %3, %9\n v_cmp_lt_u32_e64 s[20:21], %4, %8\n v_add_u32 %4, %4, %9\n v_cmp_lt_u32_e64 s[20:21], %5, %8\n v_add_u32 %5, %5, %9\n v_cmp_lt_u32_e64 s[20:21], %6, %8\n v_add_u32 %6, %6, %9\n v_cmp_lt_u32_e64 s[20:21], %7, %8\n v_add_u32 %7, %7, %9" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "s20", "s21");) }
+        if (OP == 45) { REP16(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 46) { REP16(asm volatile("v_cmp_lt_u32_e32 vcc, %0, %8\n v_cndmask_b32_e32 %0, %0, %9, vcc\n v_cmp_lt_u32_e32 vcc, %1, %8\n v_cndmask_b32_e32 %1, %1, %9, vcc\n v_cmp_lt_u32_e32 vcc, %2, %8\n v_cndmask_b32_e32 %2, %2, %9, vcc\n v_cmp_lt_u32_e32 vcc, %3, %8\n v_cndmask_b32_e32 %3, %3, %9, vcc\n v_cmp_lt_u32_e32 vcc, %4, %8\n v_cndmask_b32_e32 %4, %4, %9, vcc\n v_cmp_lt_u32_e32 vcc, %5, %8\n v_cndmask_b32_e32 %5, %5, %9, vcc\n v_cmp_lt_u32_e32 vcc, %6, %8\n v_cndmask_b32_e32 %6, %6, %9, vcc\n v_cmp_lt_u32_e32 vcc, %7, %8\n v_cndmask_b32_e32 %7, %7, %9, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
+        if (OP == 47) { REP16(asm volatile("v_cmp_lt_u32_e64 s[20:21], %0, %8\n v_cndmask_b32_e64 %0, %0, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %1, %8\n v_cndmask_b32_e64 %1, %1, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %2, %8\n v_cndmask_b32_e64 %2, %2, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %3, %8\n v_cndmask_b32_e64 %3, %3, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %4, %8\n v_cndmask_b32_e64 %4, %4, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %5, %8\n v_cndmask_b32_e64 %5, %5, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %6, %8\n v_cndmask_b32_e64 %6, %6, %9, s[20:21]\n v_cmp_lt_u32_e64 s[20:21], %7, %8\n v_cndmask_b32_e64 %7, %7, %9, s[20:21]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "s20", "s21");) }
+        if (OP == 48) { asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc"); REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc\n v_cndmask_b32_e64 %4, %4, %8, vcc\n v_cndmask_b32_e64 %5, %5, %8, vcc\n v_cndmask_b32_e64 %6, %6, %8, vcc\n v_cndmask_b32_e64 %7, %7, %8, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y));) }
+        if (OP == 49) { REP16(asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %8, vcc\n v_addc_co_u32_e32 %1, vcc, %1, %8, vcc\n v_addc_co_u32_e32 %2, vcc, %2, %8, vcc\n v_addc_co_u32_e32 %3, vcc, %3, %8, vcc\n v_addc_co_u32_e32 %4, vcc, %4, %8, vcc\n v_addc_co_u32_e32 %5, vcc, %5, %8, vcc\n v_addc_co_u32_e32 %6, vcc, %6, %8, vcc\n v_addc_co_u32_e32 %7, vcc, %7, %8, vcc" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "v"(x), "v"(y) : "vcc");) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ e ^ f ^ g ^ h;
@@ -141,5 +149,13 @@ int main() {
     run<39>("v_not_b32");
     run<40>("v_mov_dpp_wave_shr");
     run<41>("v_dot2_u32_u16");
+    run<42>("v_cndmask_e64_sgpr");
+    run<43>("v_cndmask_vcc_preset");
+    run<44>("v_cmp_e64+v_add (pairs)");
+    run<45>("v_mul_lo_u32");
+    run<46>("v_cmp_e32 vcc + v_cndmask_e32 vcc (pairs)");
+    run<47>("v_cmp_e64 sgpr + v_cndmask_e64 sgpr (pairs)");
+    run<48>("v_cndmask_e64 with vcc");
+    run<49>("v_addc_co_u32 vcc");
     return 0;
 }
