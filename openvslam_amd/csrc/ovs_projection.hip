@@ -611,8 +611,11 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
             if (t < T) {
                 const u32 j = cs + (t - cexc);
                 const uint4 en = f.g_entry[j];
+                // (the descriptor is fetched with the entry, not after the gates: the scan is a chain of
+                // dependent loads and this takes one link out of every round; a candidate that fails the
+                // gates costs 32 bytes that the frame's other queries keep in the L2 anyway)
+                const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
                 if (passes_gates<MODE>(f, c, en, occupied, blocked, true)) {
-                    const uint4 d0 = f.g_desc[2 * j], d1 = f.g_desc[2 * j + 1];
                     const u32 dist = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) + __popc(qd[3] ^ d0.w)
                                      + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) + __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
                     bool keep = true;
