@@ -685,6 +685,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
         return;
     }
     fast_load_tile(cur, tid, lane, wave, tile, tile6);
+    // (the counters and the bitmap of the first pass are cleared in front of the same barrier)
+    if (tid == 0) {
+        nwork = 0;
+        ncorner = 0;
+        total = 0;
+    }
+    if (tid < 128) {
+        keep32[tid] = 0;
+    }
     lds_barrier();
 
     int thr = min(max(p.ini_thr, 0), 255);
@@ -708,15 +717,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
     }
     #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        if (tid == 0) {
-            nwork = 0;
-            ncorner = 0;
-            total = 0;
-        }
-        if (tid < 128) {
-            keep32[tid] = 0;
-        }
-        lds_barrier();
         // stage A: rejection test, 8 strip pairs x 64 rows, two rows per thread.  Bit 8 * k + j of `md` /
         // `mbr` = pixel j (0..7) of row k passed the dark / bright test (one v_dot4 per side and strip
         // turns four flag bytes into mask bits).  Survivors are appended to the work list: a wave prefix
@@ -869,6 +869,14 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
         thr = min_thr; // cell empty at the initial threshold: retry with the minimum one
         for (int i = tid; i < 70 * 18; i += 256) {
             reinterpret_cast<u32*>(&tile6[0])[i] = (reinterpret_cast<const u32*>(&tile[0])[i] >> 2) & 0x3F3F3F3Fu;
+        }
+        if (tid == 0) {
+            nwork = 0;
+            ncorner = 0;
+            total = 0;
+        }
+        if (tid < 128) {
+            keep32[tid] = 0;
         }
         lds_barrier();
     }
