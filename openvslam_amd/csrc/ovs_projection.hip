@@ -128,6 +128,10 @@ __device__ __forceinline__ bool cell_of(const ovs_grid& g, float x, float y, int
     return 0 <= cx && cx < (int)g.num_cols && 0 <= cy && cy < (int)g.num_rows;
 }
 
+// ITEMS_LDS: the keypoint indices in cell order (the array the sort works on) live in LDS behind the
+// counters instead of in global memory: the scatter, the per-cell ordering and the final gather are
+// chains of dependent accesses, and the workgroup is the only thing running for its frame.
+template <bool ITEMS_LDS>
 __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                     const int* __restrict__ counts, int fixed_n, int cap, ovs_grid g,
                                                     u32* __restrict__ cell_start_all, u32* __restrict__ items_all,
@@ -140,7 +144,8 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
     const ovs_keypoint* kps = kps_all + (size_t)f * cap;
     const uint8_t* desc = desc_all + (size_t)f * cap * 32;
     u32* cell_start = cell_start_all + (size_t)f * (ncell + 1);
-    u32* items = items_all + (size_t)f * cap;
+    const int ncell_ = (int)(g.num_cols * g.num_rows);
+    u32* items = ITEMS_LDS ? sm + 2 * ncell_ + 1 : items_all + (size_t)f * cap;
     uint4* entry = entry_all + (size_t)f * cap;
     uint4* gdesc = gdesc_all + (size_t)f * cap * 2;
     u32* cnt = sm;             // ncell + 1
@@ -1395,6 +1400,8 @@ void launch_candidates(dim3 grid, const proj_problem* d_prob, const proj_params&
 }
 
 int grid_lds_bytes(const ovs_grid& g) { return static_cast<int>((2 * g.num_cols * g.num_rows + 1) * sizeof(u32)); }
+// the index array fits in LDS next to the counters (64 KB of dynamic LDS need no attribute)
+bool grid_items_in_lds(const ovs_grid& g, int cap) { return grid_lds_bytes(g) + 4ll * cap <= 64 * 1024; }
 
 int validate_frame(const ovs_frame_view* f) {
     if (!f || f->num_keypts < 0 || (f->num_keypts > 0 && (!f->undist_keypts || !f->descriptors)) || !f->scale_factors
@@ -1459,9 +1466,17 @@ void stage_frame(const ovs_frame_view* f, carver& cv, host_stager& hs, staged_fr
 // Builds the grid of a staged frame (after the stager's upload has been enqueued on `st`).
 void launch_grid_build(const staged_frame& sf, hipStream_t st) {
     const frame_dev& d = sf.dev;
-    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(1), dim3(256), grid_lds_bytes(d.grid), st,
-               d.kps, d.desc, static_cast<const int*>(nullptr), d.n, std::max(d.n, 1), d.grid,
-               const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
+    const int cap1 = std::max(d.n, 1);
+    if (grid_items_in_lds(d.grid, cap1)) {
+        OVS_LAUNCH("k_grid_build", k_grid_build<true>, dim3(1), dim3(256), grid_lds_bytes(d.grid) + 4 * cap1, st,
+                   d.kps, d.desc, static_cast<const int*>(nullptr), d.n, cap1, d.grid,
+                   const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
+    }
+    else {
+        OVS_LAUNCH("k_grid_build", k_grid_build<false>, dim3(1), dim3(256), grid_lds_bytes(d.grid), st,
+                   d.kps, d.desc, static_cast<const int*>(nullptr), d.n, cap1, d.grid,
+                   const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
+    }
 }
 
 // Runs one projection-matching problem given host views.
@@ -2485,8 +2500,14 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
                d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, sf_arg, num_scale_levels,
                d_cell_start, d_entry, d_gdesc, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,
                d_matched, d_num_matches, d_err, d_prob);
-    OVS_LAUNCH("k_grid_build", k_grid_build, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
-               d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
+    if (grid_items_in_lds(*grid, cap)) {
+        OVS_LAUNCH("k_grid_build", k_grid_build<true>, dim3(n_frames), dim3(256), grid_lds_bytes(*grid) + 4 * cap, st,
+                   d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
+    }
+    else {
+        OVS_LAUNCH("k_grid_build", k_grid_build<false>, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
+                   d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
+    }
     if (n_frames > 1) {
         constexpr int QPB = 256 / kGroup;
         launch_candidates(dim3((cap + QPB - 1) / QPB, n_frames - 1), d_prob, pp, st);
