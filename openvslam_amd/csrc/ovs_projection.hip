@@ -1403,6 +1403,34 @@ int grid_lds_bytes(const ovs_grid& g) { return static_cast<int>((2 * g.num_cols 
 // the index array fits in LDS next to the counters (64 KB of dynamic LDS need no attribute)
 bool grid_items_in_lds(const ovs_grid& g, int cap) { return grid_lds_bytes(g) + 4ll * cap <= 64 * 1024; }
 
+// Launches k_grid_build for `frames` frames of at most `cap` keypoints.  Dynamic LDS beyond the default
+// limit (a grid of up to 16384 cells needs 128 KB of counters) is granted once per (device, kernel
+// instance), to the most the kernel can ask for, and never lowered.
+constexpr int kGridMaxLds = (2 * 16384 + 1) * 4 + 64;
+int launch_grid_build_kernel(int frames, const ovs_keypoint* d_kps, const uint8_t* d_desc, const int* d_counts, int fixed_n, int cap, const ovs_grid& g,
+                             u32* d_cell_start, u32* d_items, uint4* d_entry, uint4* d_gdesc, hipStream_t st) {
+    const bool in_lds = grid_items_in_lds(g, cap);
+    const int bytes = grid_lds_bytes(g) + (in_lds ? 4 * cap : 0);
+    if (bytes > kGridMaxLds) {
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "grid build: LDS plan exceeds the limit");
+    }
+    auto kernel = in_lds ? k_grid_build<true> : k_grid_build<false>;
+    if (bytes > 48 * 1024) {
+        static std::mutex mu;
+        static std::set<std::pair<int, const void*>> granted;
+        int dev = 0;
+        OVS_HIP(hipGetDevice(&dev));
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!granted.count({dev, fn})) {
+            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kGridMaxLds));
+            granted.insert({dev, fn});
+        }
+    }
+    OVS_LAUNCH("k_grid_build", kernel, dim3(frames), dim3(256), bytes, st, d_kps, d_desc, d_counts, fixed_n, cap, g, d_cell_start, d_items, d_entry, d_gdesc);
+    return OVS_OK;
+}
+
 int validate_frame(const ovs_frame_view* f) {
     if (!f || f->num_keypts < 0 || (f->num_keypts > 0 && (!f->undist_keypts || !f->descriptors)) || !f->scale_factors
         || f->num_scale_levels <= 0) {
@@ -1464,19 +1492,10 @@ void stage_frame(const ovs_frame_view* f, carver& cv, host_stager& hs, staged_fr
 }
 
 // Builds the grid of a staged frame (after the stager's upload has been enqueued on `st`).
-void launch_grid_build(const staged_frame& sf, hipStream_t st) {
+int launch_grid_build(const staged_frame& sf, hipStream_t st) {
     const frame_dev& d = sf.dev;
-    const int cap1 = std::max(d.n, 1);
-    if (grid_items_in_lds(d.grid, cap1)) {
-        OVS_LAUNCH("k_grid_build", k_grid_build<true>, dim3(1), dim3(256), grid_lds_bytes(d.grid) + 4 * cap1, st,
-                   d.kps, d.desc, static_cast<const int*>(nullptr), d.n, cap1, d.grid,
-                   const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
-    }
-    else {
-        OVS_LAUNCH("k_grid_build", k_grid_build<false>, dim3(1), dim3(256), grid_lds_bytes(d.grid), st,
-                   d.kps, d.desc, static_cast<const int*>(nullptr), d.n, cap1, d.grid,
-                   const_cast<u32*>(d.cell_start), sf.d_items, const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc));
-    }
+    return launch_grid_build_kernel(1, d.kps, d.desc, nullptr, d.n, std::max(d.n, 1), d.grid, const_cast<u32*>(d.cell_start), sf.d_items,
+                                    const_cast<uint4*>(d.g_entry), const_cast<uint4*>(d.g_desc), st);
 }
 
 // Runs one projection-matching problem given host views.
@@ -1585,7 +1604,12 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     hs.put(d_prob, &P, sizeof(P));
     OVS_HIP(hs.upload());
 
-    launch_grid_build(sfrm, st);
+    {
+        const int grc = launch_grid_build(sfrm, st);
+        if (grc != OVS_OK) {
+            return grc;
+        }
+    }
     if (nq) {
         constexpr int QPB = 256 / kGroup;
         launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
@@ -1983,7 +2007,12 @@ int ovs_get_keypoints_in_cell(const ovs_frame_view* frm, int n_queries,
         hs.put(d_hi, max_level, nq * 4);
     }
     OVS_HIP(hs.upload());
-    launch_grid_build(sfrm, st);
+    {
+        const int grc = launch_grid_build(sfrm, st);
+        if (grc != OVS_OK) {
+            return grc;
+        }
+    }
     OVS_LAUNCH("k_window_list", k_window_list, dim3((n_queries + 3) / 4), dim3(256), 0, st, fd, n_queries, d_xy, d_m,
                min_level ? d_lo : nullptr, max_level ? d_hi : nullptr, 1, d_cnt, static_cast<const u32*>(nullptr), static_cast<u32*>(nullptr));
     std::vector<u32> counts(nq);
@@ -2500,13 +2529,8 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
                d_kps, d_desc, d_counts, n_frames, cap, d_reproj_xy, *grid, d_sf, sf_arg, num_scale_levels,
                d_cell_start, d_entry, d_gdesc, static_cast<int>(ncell), d_sl, d_ang, d_valid, d_lists, d_totals, d_acc,
                d_matched, d_num_matches, d_err, d_prob);
-    if (grid_items_in_lds(*grid, cap)) {
-        OVS_LAUNCH("k_grid_build", k_grid_build<true>, dim3(n_frames), dim3(256), grid_lds_bytes(*grid) + 4 * cap, st,
-                   d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
-    }
-    else {
-        OVS_LAUNCH("k_grid_build", k_grid_build<false>, dim3(n_frames), dim3(256), grid_lds_bytes(*grid), st,
-                   d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc);
+    if ((rc = launch_grid_build_kernel(n_frames, d_kps, d_desc, d_counts, 0, cap, *grid, d_cell_start, d_items, d_entry, d_gdesc, st)) != OVS_OK) {
+        return rc;
     }
     if (n_frames > 1) {
         constexpr int QPB = 256 / kGroup;

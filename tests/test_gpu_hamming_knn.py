@@ -88,6 +88,51 @@ def test_get_keypoints_in_cell(seed, n, nq):
         assert res[0][0][-1] > 1000
 
 
+@pytest.mark.parametrize("cols,rows,n", [(128, 128, 3000), (100, 90, 20000), (16, 12, 3000)])
+def test_get_keypoints_in_cell_other_grids(cols, rows, n):
+    # grids other than the reference's 64 x 48: the largest supported one (16384 cells: 128 KB of cell
+    # counters in LDS), one whose counters alone pass 64 KB with more keypoints than the LDS index array
+    # holds, and a coarse one
+    rng = np.random.default_rng(cols * 1000 + rows)
+    nq = 300
+    kps = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 1920, n)
+    kps["y"] = rng.uniform(0, 960, n)
+    kps["octave"] = rng.integers(0, 8, n)
+    desc = np.zeros((n, 32), np.uint8)
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    view = A.make_frame_view(kps, desc, sf, A.make_grid(0.0, 0.0, 1920.0, 960.0, cols, rows))
+    xy = np.stack([rng.uniform(-50, 2000, nq), rng.uniform(-50, 1000, nq)], axis=1).astype(np.float32)
+    margin = rng.uniform(1, 60, nq).astype(np.float32)
+    lo = np.full(nq, -1, np.int32)
+    hi = np.full(nq, -1, np.int32)
+    cap = 2000000
+    res = []
+    for lib_, pre, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+        idx = np.zeros(cap, np.uint32)
+        off = np.zeros(nq + 1, np.uint32)
+        rc = getattr(lib_, pre + "get_keypoints_in_cell")(view.ref(), nq, A.ptr(xy, A.f32p), A.ptr(margin, A.f32p), A.ptr(lo, A.i32p),
+                                                        A.ptr(hi, A.i32p), A.ptr(idx, A.u32p), cap, A.ptr(off, A.u32p), *extra)
+        assert rc == 0
+        res.append((off, idx[:off[-1]].copy()))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+    assert res[0][0][-1] > 100
+
+
+def test_grid_with_too_many_cells_is_refused():
+    kps = np.zeros(10, dtype=A.KEYPOINT_DTYPE)
+    view = A.make_frame_view(kps, np.zeros((10, 32), np.uint8), np.ones(8, np.float32), A.make_grid(0.0, 0.0, 640.0, 480.0, 129, 128))
+    xy = np.array([[100.0, 100.0]], np.float32)
+    margin = np.array([5.0], np.float32)
+    lo = np.array([-1], np.int32)
+    idx = np.zeros(10, np.uint32)
+    off = np.zeros(2, np.uint32)
+    rc = _lib.lib().ovs_get_keypoints_in_cell(view.ref(), 1, A.ptr(xy, A.f32p), A.ptr(margin, A.f32p), A.ptr(lo, A.i32p), A.ptr(lo, A.i32p),
+                                              A.ptr(idx, A.u32p), 10, A.ptr(off, A.u32p), 0)
+    assert rc != 0
+
+
 def test_get_keypoints_in_cell_capacity_error():
     n = 500
     kps = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
