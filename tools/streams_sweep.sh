@@ -1,5 +1,6 @@
+# usage (GPU box): bash tools/streams_sweep.sh   the KITTI step with different numbers of streams / sub-batch sizes
 cd $GRAFT_REPO_ROOT
-for cfg in "1 255" "2 510" "3 765" "4 1020" "6 1530" "8 2040" "2 1020" "8 1020"; do set -- $cfg
+for cfg in "2 510" "3 765" "4 1020" "6 1530" "8 2040" "2 1020" "3 1020" "5 1020" "6 1020" "10 1020" "12 1020"; do set -- $cfg
   timeout -k 10 200 python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --streams $1 --batch $2 > gpurun_out/st_$1_$2.log 2>&1 || { echo fail; tail -3 gpurun_out/st_$1_$2.log; exit 1; }
   python3 - "$1" "$2" <<'PY'
 import json,sys
