@@ -6,7 +6,7 @@ buffer sits in guarded memory and starts filled with a chosen byte), not its tim
 behaviour.
 
     run_qt_emu.py [--hip FILE] [--patched] [--fill 0xFF] [--levels 8] [--n 2000] [--size 1241x376]
-                  [--scale 1.2] [--image noise|synth] [--seed 1] [--strict-lds]
+                  [--scale 1.2] [--image noise|synth|faint|sparse] [--seed 1] [--strict-lds] [--no-build]
 
 --hip      kernel source to cut the quadtree from (default: openvslam_amd/csrc/ovs_orb.hip)
 --patched  the source has the NODES_LDS template parameter (the global-workspace experiment)
@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--image", default="noise")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--work", default="/tmp/qt_emu")
+    ap.add_argument("--no-build", action="store_true", help="reuse the emulator binary in the work directory")
+    ap.add_argument("--ini-thr", type=int, default=20)
+    ap.add_argument("--min-thr", type=int, default=7)
     ap.add_argument("--strict-lds", action="store_true", help="a read past the LDS allocation is an error (the hardware returns 0)")
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
@@ -45,19 +48,32 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
 
     inc = os.path.join(a.work, "qt_kernel.inc")
-    subprocess.run([sys.executable, os.path.join(here, "gen_quadtree_emu.py"), a.hip, inc], check=True)
     exe = os.path.join(a.work, "qt_emu_patched" if a.patched else "qt_emu")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-rdynamic", "-Wno-unknown-pragmas",
-           "-I", a.work, "-I", here, os.path.join(here, "qt_emu_main.cc"), "-o", exe]
-    if a.patched:
-        cmd.insert(1, "-DQT_PATCHED")
-    subprocess.run(cmd, check=True)
+    if not (a.no_build and os.path.exists(exe)):
+        subprocess.run([sys.executable, os.path.join(here, "gen_quadtree_emu.py"), a.hip, inc], check=True)
+        cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-rdynamic", "-Wno-unknown-pragmas",
+               "-I", a.work, "-I", here, os.path.join(here, "qt_emu_main.cc"), "-o", exe]
+        if a.patched:
+            cmd.insert(1, "-DQT_PATCHED")
+        subprocess.run(cmd, check=True)
 
     if a.image == "noise":
         img = np.random.default_rng(a.seed).integers(0, 256, (h, w), dtype=np.uint8)
+    elif a.image == "faint":
+        # low contrast: most cells only answer at the minimum threshold, many stay empty
+        rng = np.random.default_rng(a.seed)
+        img = np.clip(128 + rng.normal(0, 3.5, (h, w)), 0, 255).astype(np.uint8)
+    elif a.image == "sparse":
+        # a handful of isolated corners: levels with fewer candidates than initial nodes
+        rng = np.random.default_rng(a.seed)
+        img = np.full((h, w), 100, np.uint8)
+        for _ in range(int(rng.integers(1, 12))):
+            y, x = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+            img[y:y + 8, x:x + 8] = 220
     else:
         img = synth.make_frame(w, h, seed=a.seed)
-    ref = oracle.OrbExtractor(max_num_keypts=a.n, num_levels=a.levels, scale_factor=a.scale)
+    ref = oracle.OrbExtractor(max_num_keypts=a.n, num_levels=a.levels, scale_factor=a.scale,
+                              ini_fast_thr=a.ini_thr, min_fast_thr=a.min_thr)
     rk, _ = ref.extract(img)
     quotas = ref.num_keypts_per_level()
     words = [a.levels]
