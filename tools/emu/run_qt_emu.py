@@ -89,7 +89,7 @@ def main():
     r = subprocess.run([exe, fin, fout, a.fill] + (["strict"] if a.strict_lds else []))
     if r.returncode != 0:
         print("emulator exit code", r.returncode)
-        return 1
+        return 2 if r.returncode == 2 else 1  # 2: the guarded address space could not be reserved
 
     out = np.fromfile(fout, dtype=np.int32)
     pos, bad = 0, 0
