@@ -1229,7 +1229,35 @@ __device__ __forceinline__ short4 child_bounds(short4 b, int c) {
 }
 
 // In-place exclusive scan of a[0..n) in LDS by the whole workgroup; returns the total.
-__device__ u32 block_excl_scan(u32* a, int n, u32* red) {
+// Workgroup barrier of the quadtree kernel.  NODES_LDS: the node arrays are in LDS, a plain barrier.
+// Otherwise they are in a global workspace, where atomics execute in the L2 while plain loads may be
+// served by the compute unit's vector cache: stores and atomics are complete before the barrier and
+// the cache is invalidated after it.
+template <bool NODES_LDS>
+__device__ __forceinline__ void qt_sync() {
+    if (NODES_LDS) {
+        __syncthreads();
+    }
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+// Node array of the quadtree kernel.  In LDS an index is used as it is (a read past the allocation returns
+// 0 there and a write is dropped).  In the global workspace (CLAMP) every index is clamped to the array, so
+// that no path through the kernel, whatever it has computed, touches memory outside its workgroup's slice.
+template <typename T, bool CLAMP>
+struct qt_arr {
+    T* p;
+    u32 last; // index of the last element
+    __device__ __forceinline__ T& operator[](u32 i) const { return p[CLAMP ? min(i, last) : i]; }
+    __device__ __forceinline__ T& operator[](int i) const { return (*this)[(u32)i]; }
+};
+
+template <bool NODES_LDS, typename A>
+__device__ u32 block_excl_scan(A a, int n, u32* red) {
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
     const int per = (n + nt - 1) / nt;
     const int b = min(tid * per, n), e = min(b + per, n);
@@ -1238,11 +1266,11 @@ __device__ u32 block_excl_scan(u32* a, int n, u32* red) {
         sum += a[i];
     }
     const u32 inc = (u32)wave_incl_scan((int)sum);
-    __syncthreads(); // red may still be read by a previous call
+    qt_sync<NODES_LDS>(); // red may still be read by a previous call
     if (lane == 63) {
         red[wave] = inc;
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     u32 woff = 0, tot = 0;
     for (int w = 0; w < nwaves; ++w) {
         const u32 v = red[w];
@@ -1255,7 +1283,7 @@ __device__ u32 block_excl_scan(u32* a, int n, u32* red) {
         a[i] = run;
         run += v;
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     return tot;
 }
 
@@ -1267,7 +1295,8 @@ __device__ __forceinline__ int nonzero4(const u32* c) {
 // first passes of a level have a handful of nodes for thousands of candidates, and LDS atomics on one
 // address are served one lane at a time): the wave peels off one distinct target per round and its
 // first lane adds the number of lanes that share it.  Called by all lanes of the wave.
-__device__ __forceinline__ void lds_count_aggregated(u32* ctr, u32 target, bool valid) {
+template <typename A>
+__device__ __forceinline__ void lds_count_aggregated(A ctr, u32 target, bool valid) {
     u64 todo = __ballot(valid);
     const int lane = threadIdx.x & 63;
     while (todo) {
@@ -1319,9 +1348,9 @@ __device__ __forceinline__ void for_each_candidate(const u32* __restrict__ cnode
 // instead of five per candidate.
 //   stage1(n)                      an extra word read together with the record of node n
 //   stage2(n, rec, b, aux, x, y)   the new node id (may read one more LDS word)
-template <typename Stage1, typename Stage2>
-__device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* __restrict__ cnode, int N, const u32* nc_from, const short4* nb_from,
-                                              const u32* nc_to, const short4* nb_to, u32* votes, int n_votes, Stage1&& stage1, Stage2&& stage2) {
+template <typename NC, typename NB, typename Stage1, typename Stage2>
+__device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* __restrict__ cnode, int N, NC nc_from, NB nb_from,
+                                              NC nc_to, NB nb_to, NC votes, int n_votes, Stage1&& stage1, Stage2&& stage2) {
     // n_votes = number of vote counters of this pass (the same in every thread)
     const int tid = threadIdx.x, nt = blockDim.x;
     const bool aggregate = n_votes <= kAggregateBelow;
@@ -1344,6 +1373,11 @@ __device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* 
 #pragma unroll
         for (int u = 0; u < kCandDepth; ++u) {
             nn[u] = stage2(cd[u].y & kCnt, rec[u], b[u], aux[u], (int)(cd[u].x & 0xFFFF), (int)(cd[u].x >> 16));
+            // A lane past the last candidate re-reads candidate N - 1, possibly after its owner has moved it:
+            // the node id it then holds belongs to the other list and the id derived from it is arbitrary.
+            // Nothing such a lane computes is used, but the record reads below must stay inside the arrays
+            // (in LDS a read past the allocation returns 0; in the global workspace it is a fault).
+            nn[u] = i0 + u * nt < N ? nn[u] : 0u;
         }
         u32 rec2[kCandDepth];
         short4 b2[kCandDepth];
@@ -1370,29 +1404,40 @@ __device__ __forceinline__ void move_and_vote(const u32* __restrict__ cxy, u32* 
     }
 }
 
+// A launch covers the levels level0 .. level0 + gridDim.y - 1 and sizes its node arrays for `ncap`, the
+// largest node capacity among them (72 bytes per node).  NODES_LDS: the arrays are in LDS (levels whose
+// quota fits: up to about 1130 keypoints per level); otherwise in `node_ws`, one slice per workgroup
+// (slower by the latency of every access, but any quota below 8188 per level works).
+constexpr int kQtWordsPerNode = 18;
+constexpr int kQtMaxPasses = 64;
+template <bool NODES_LDS>
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* __restrict__ slots, const u32* __restrict__ cell_counts,
                                                          u32* __restrict__ cand_xy_all, u32* __restrict__ cand_node_all,
-                                                         u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count) {
+                                                         u32* __restrict__ lvl_xy, uint8_t* __restrict__ lvl_resp, int* __restrict__ lvl_count,
+                                                         int level0, int ncap, u32* node_ws) {
     extern __shared__ u32 smem[];
     // Workgroups are dealt round-robin to the 8 XCDs in launch order and a level-0 workgroup runs
     // about three times as long as one of the last level: with the frame as the fast grid dimension
     // every XCD gets the same mix of levels, and the long workgroups start first.
-    const int level = blockIdx.y, frame = blockIdx.x;
+    const int level = level0 + (int)blockIdx.y, frame = blockIdx.x;
     const level_geom& g = p.lv[level];
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int ncap = p.max_ncap;
+    u32* nodes = NODES_LDS ? smem : node_ws + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)ncap * kQtWordsPerNode);
 
-    short4* nb_cur = reinterpret_cast<short4*>(smem);
-    short4* nb_nxt = nb_cur + ncap;
-    u32* nc_cur = reinterpret_cast<u32*>(nb_nxt + ncap);
-    u32* nc_nxt = nc_cur + ncap;
-    u32* cc = nc_nxt + ncap;   // 4 * ncap child counters of the current list, later child ids
-    u32* cc2 = cc + 4 * ncap;  // the same for the list being built
-    u32* t0 = cc2 + 4 * ncap;
-    u32* t1 = t0 + ncap;
-    u32* t2 = t1 + ncap;
-    u32* t3 = t2 + ncap;
-    u32* cellpref = t3 + ncap; // max_cells + 1
+    typedef qt_arr<u32, !NODES_LDS> arr_u;
+    typedef qt_arr<short4, !NODES_LDS> arr_b;
+    const u32 last1 = (u32)ncap - 1, last4 = 4 * (u32)ncap - 1;
+    arr_b nb_cur{reinterpret_cast<short4*>(nodes), last1};
+    arr_b nb_nxt{nb_cur.p + ncap, last1};
+    arr_u nc_cur{reinterpret_cast<u32*>(nb_nxt.p + ncap), last1};
+    arr_u nc_nxt{nc_cur.p + ncap, last1};
+    arr_u cc{nc_nxt.p + ncap, last4};   // 4 * ncap child counters of the current list, later child ids
+    arr_u cc2{cc.p + 4 * ncap, last4};  // the same for the list being built
+    arr_u t0{cc2.p + 4 * ncap, last1};
+    arr_u t1{t0.p + ncap, last1};
+    arr_u t2{t1.p + ncap, last1};
+    arr_u t3{t2.p + ncap, last1};
+    u32* cellpref = NODES_LDS ? t3.p + ncap : smem; // max_cells + 1 (always in LDS, like the scan scratch and the scalars)
     u32* red = cellpref + p.max_cells + 1; // 16
     u32* sh = red + 16;                    // scalars
 
@@ -1405,8 +1450,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     for (int c = tid; c < ncells; c += nt) {
         cellpref[c] = cell_counts[cell0 + c];
     }
-    __syncthreads();
-    const int N = (int)block_excl_scan(cellpref, ncells, red);
+    qt_sync<NODES_LDS>();
+    const int N = (int)block_excl_scan<NODES_LDS>(cellpref, ncells, red);
     if (tid == 0) {
         cellpref[ncells] = N;
     }
@@ -1419,8 +1464,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     // smallest x whose quotient reaches k; those few thresholds are found once with the same
     // division and the per-candidate work becomes integer compares.  (t2 / t3 hold them: the
     // node arrays have at least 4 * nx * ny + 8 entries.)
-    u32* thx = t2;
-    u32* thy = t3;
+    arr_u thx = t2;
+    arr_u thy = t3;
     for (int k = tid; k < g.nx + g.ny; k += nt) {
         const bool is_x = k < g.nx;
         const int kk = is_x ? k : k - g.nx;
@@ -1431,7 +1476,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         }
         (is_x ? thx : thy)[kk] = (u32)x; // threshold 0 is 0
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
 
     // dense candidates in the reference's order: cells row-major, raster order inside a cell
     for (int i0 = tid; i0 < N; i0 += 4 * nt) {
@@ -1486,12 +1531,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             }
         }
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     for (int q = tid; q < n0; q += nt) {
         t1[q] = t0[q] != 0;
     }
-    __syncthreads();
-    int S = (int)block_excl_scan(t1, n0, red);
+    qt_sync<NODES_LDS>();
+    int S = (int)block_excl_scan<NODES_LDS>(t1, n0, red);
     for (int q = tid; q < n0; q += nt) {
         const u32 cnt = t0[q];
         if (cnt) {
@@ -1508,16 +1553,20 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     for (int i = tid; i < 4 * S; i += nt) {
         cc[i] = 0;
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     // compact node ids + votes for the first sweep
     move_and_vote(
         cxy, cnode, N, t1, nb_cur, nc_cur, nb_cur, cc, 4 * S, [&](u32) { return 0u; },
         [&](u32, u32 compact_id, short4, u32, int, int) { return compact_id; });
-    __syncthreads();
+    qt_sync<NODES_LDS>();
 
     bool filled = false;
     bool overflow = false;
     int front = 0; // number of freshly created nodes at the head of the list
+    // Every pass of either loop splits at least one node one level deeper, and a node of a 4134-px level
+    // cannot be halved more than 13 times: the loops end by themselves long before this many passes.  The
+    // bound only makes sure that every wave reaches the end of the kernel whatever the node arrays hold.
+    int passes_left = kQtMaxPasses;
 
     // ---- orb_extractor.cc:411-442: split every non-leaf node per sweep -------------------------
     // invariant at the top: cc holds the child counts of every non-leaf node of the current list
@@ -1532,12 +1581,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             const bool leaf = nc_cur[q] & kLeaf;
             t0[q] = leaf ? 0x10000u : (u32)nonzero4(&cc[4 * q]);
         }
-        __syncthreads();
-        const u32 both = block_excl_scan(t0, S, red);
+        qt_sync<NODES_LDS>();
+        const u32 both = block_excl_scan<NODES_LDS>(t0, S, red);
         const int C = (int)(both & 0xFFFFu);
         const int Lf = (int)(both >> 16);
         const int Snew = C + Lf;
-        if (Snew > ncap) {
+        if (Snew > ncap || --passes_left < 0) {
             overflow = true;
             break;
         }
@@ -1573,18 +1622,18 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         for (int i = tid; i < 4 * Snew; i += nt) {
             cc2[i] = 0;
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         // move every candidate to its child and vote for the next split of that child
         move_and_vote(
             cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, 4 * Snew, [&](u32) { return 0u; },
             [&](u32 n, u32 rec, short4 b, u32, int x, int y) { return cc[4 * n + ((rec & kLeaf) ? 0 : child_of(b, x, y))]; });
         const int pool = (int)sh[0];
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         {
-            short4* tb = nb_cur;
+            arr_b tb = nb_cur;
             nb_cur = nb_nxt;
             nb_nxt = tb;
-            u32* tc = nc_cur;
+            arr_u tc = nc_cur;
             nc_cur = nc_nxt;
             nc_nxt = tc;
             tc = cc;
@@ -1613,8 +1662,8 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         if (tid == 0) {
             sh[1] = 0x7FFFFFFFu;
         }
-        __syncthreads();
-        const int P = (int)block_excl_scan(t0, front, red);
+        qt_sync<NODES_LDS>();
+        const int P = (int)block_excl_scan<NODES_LDS>(t0, front, red);
         if (P == 0) {
             break;
         }
@@ -1623,13 +1672,13 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
                 t1[t0[q]] = q;
             }
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         // stable sort by count descending (rank by counting over a dense copy of the counts; the
         // pool is at most a few hundred nodes)
         for (int k = tid; k < P; k += nt) {
             t3[k] = nc_cur[t1[k]] & kCnt;
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         for (int k = tid; k < P; k += nt) {
             const u32 ck = t3[k];
             int rank = 0;
@@ -1639,12 +1688,12 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
             }
             t2[rank] = t1[k];
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         for (int k = tid; k < P; k += nt) {
             t0[k] = nonzero4(&cc[4 * t2[k]]);
         }
-        __syncthreads();
-        block_excl_scan(t0, P, red);
+        qt_sync<NODES_LDS>();
+        block_excl_scan<NODES_LDS>(t0, P, red);
         // first pool entry (in sorted order) at which the list reaches the quota
         for (int k = tid; k < P; k += nt) {
             const int created = (int)t0[k] + nonzero4(&cc[4 * t2[k]]);
@@ -1652,24 +1701,24 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
                 atomicMin(&sh[1], (u32)k);
             }
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         const int kstar = min((int)sh[1], P - 1);
         const int Cn = (int)t0[kstar] + nonzero4(&cc[4 * t2[kstar]]);
         const int Snew = Cn + S - (kstar + 1);
         const bool filled_now = quota <= Snew;
-        if (Snew > ncap) {
+        if (Snew > ncap || --passes_left < 0) {
             overflow = true;
             break;
         }
         for (int k = tid; k <= kstar; k += nt) {
             nc_cur[t2[k]] |= kProc;
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         for (int q = tid; q < S; q += nt) {
             t3[q] = (nc_cur[q] & kProc) ? 0 : 1;
         }
-        __syncthreads();
-        block_excl_scan(t3, S, red);
+        qt_sync<NODES_LDS>();
+        block_excl_scan<NODES_LDS>(t3, S, red);
         for (int k = tid; k <= kstar; k += nt) {
             const u32 q = t2[k];
             const short4 b = nb_cur[q];
@@ -1696,19 +1745,19 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
         for (int i = tid; i < 4 * Snew; i += nt) {
             cc2[i] = 0;
         }
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         move_and_vote(
             cxy, cnode, N, nc_cur, nb_cur, nc_nxt, nb_nxt, cc2, 4 * Snew, [&](u32 n) { return t3[n]; },
             [&](u32 n, u32 rec, short4 b, u32 kept_before, int x, int y) {
                 const u32 child_id = cc[4 * n + ((rec & kProc) ? child_of(b, x, y) : 0)];
                 return (rec & kProc) ? child_id : (u32)Cn + kept_before;
             });
-        __syncthreads();
+        qt_sync<NODES_LDS>();
         {
-            short4* tb = nb_cur;
+            arr_b tb = nb_cur;
             nb_cur = nb_nxt;
             nb_nxt = tb;
-            u32* tc = nc_cur;
+            arr_u tc = nc_cur;
             nc_cur = nc_nxt;
             nc_nxt = tc;
             tc = cc;
@@ -1730,15 +1779,15 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(plan_dev p, const u32* 
     }
 
     // ---- orb_extractor.cc:568-590: first keypoint of maximum response per node ------------------
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     for (int q = tid; q < S; q += nt) {
         cc[q] = 0;
     }
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     for_each_candidate(cnode, N, [&](int i, u32 cd) {
         atomicMax(&cc[cd & kCnt], (cd & 0xFF000000u) | (0xFFFFFFu - (u32)i));
     });
-    __syncthreads();
+    qt_sync<NODES_LDS>();
     const long long ob = (long long)frame * p.kp_total_cap + g.kp_base;
     for (int q = tid; q < S; q += nt) {
         const u32 v = cc[q];
@@ -2106,7 +2155,7 @@ struct ovs_orb {
 
     // batch-capacity dependent buffers
     int batch_cap = 0;
-    ovs::dev_buffer pyr, blur, slots, cell_counts, cand, lvl_xy, lvl_resp, lvl_count;
+    ovs::dev_buffer pyr, blur, slots, cell_counts, cand, lvl_xy, lvl_resp, lvl_count, qt_ws;
     // staging for the single-frame host entry point
     ovs::dev_buffer st_img, st_mask, st_out;  // st_out: count (256 B), keypoints, descriptors
     ovs::pinned_buffer pin_in, pin_out;
@@ -2238,9 +2287,21 @@ bool is_area_fast_2x(int sw, int sh, int dw, int dh) {
 // grid size of a kernel that maps its blocks with xcd_contiguous_block()
 unsigned xcd_grid(long long total) { return static_cast<unsigned>(((total + 7) / 8) * 8); }
 
-size_t quadtree_lds_bytes(const plan_dev& p) {
+size_t quadtree_lds_bytes(const plan_dev& p, int ncap) {
     // nb x2 (8 B), nc x2 (4 B), cc x2 (16 B), t0..t3 (16 B) per node + cell prefix + scratch
-    return static_cast<size_t>(p.max_ncap) * (16 + 8 + 32 + 16) + static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
+    static_assert(kQtWordsPerNode * 4 == 16 + 8 + 32 + 16, "node record");
+    return static_cast<size_t>(ncap) * (kQtWordsPerNode * 4) + static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
+}
+constexpr size_t kQtMaxLds = 160 * 1024;
+// levels [0, first_lds_level) keep their node arrays in the global workspace
+int quadtree_first_lds_level(const plan_dev& p) {
+    int first = 0;
+    for (int l = 0; l < p.num_levels; ++l) {
+        if (quadtree_lds_bytes(p, p.lv[l].ncap) > kQtMaxLds) {
+            first = l + 1;
+        }
+    }
+    return first;
 }
 
 int build_plan(ovs_orb* h, int width, int height) {
@@ -2335,8 +2396,9 @@ int build_plan(ovs_orb* h, int width, int height) {
     p.frame_pyr_bytes = (pyr_off + 255) & ~255ll;
     p.frame_blur_bytes = (blur_off + 255) & ~255ll;
     p.frame_cand_cap = cand_base;
-    if (quadtree_lds_bytes(p) > 160 * 1024) {
-        return ovs::fail(OVS_ERR_UNSUPPORTED, "keypoint quota per level too large for the on-chip quadtree");
+    if (p.max_ncap >= 16384) {
+        // (the sweeps pack two node counts of at most 4 * ncap into one 32-bit word)
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "more than 8187 keypoints per pyramid level are not supported");
     }
     {
         // dynamic LDS of the quadtree kernel: granted once per device, to the most a workgroup can
@@ -2347,7 +2409,7 @@ int build_plan(ovs_orb* h, int width, int height) {
         OVS_HIP(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lock(mu);
         if (!granted.count(dev)) {
-            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            OVS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             granted.insert(dev);
         }
     }
@@ -2394,6 +2456,14 @@ int ensure_buffers(ovs_orb* h, int n_frames) {
     if ((rc = h->lvl_xy.reserve(B * p.kp_total_cap * sizeof(u32))) != OVS_OK) return rc;
     if ((rc = h->lvl_resp.reserve(B * p.kp_total_cap)) != OVS_OK) return rc;
     if ((rc = h->lvl_count.reserve((B * p.num_levels + 16) * sizeof(int))) != OVS_OK) return rc; // + 16: k_orient_desc reads 16 entries from a frame's first
+    if (const int gl = quadtree_first_lds_level(p)) {
+        // node arrays of the levels whose quota does not fit in LDS: one slice per (level, frame)
+        int ncap = 0;
+        for (int l = 0; l < gl; ++l) {
+            ncap = std::max(ncap, p.lv[l].ncap);
+        }
+        if ((rc = h->qt_ws.reserve(B * gl * static_cast<size_t>(ncap) * kQtWordsPerNode * sizeof(u32))) != OVS_OK) return rc;
+    }
     h->batch_cap = n_frames;
     return OVS_OK;
 }
@@ -2713,9 +2783,32 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
         OVS_LAUNCH("k_fast_cells", k_fast_cells, dim3(xcd_grid(p.total_cells), std::min(n_frames - f0, 65535)), dim3(256), 0, stream,
                    p, src, h->cell_tab.as<fast_cell_rec>(), h->slots.as<u32>(), h->cell_counts.as<u32>(), f0);
     }
-    OVS_LAUNCH("k_quadtree", k_quadtree, dim3(n_frames, p.num_levels), dim3(kQtThreads), quadtree_lds_bytes(p), stream,
-               p, h->slots.as<u32>(), h->cell_counts.as<u32>(), h->cand.as<u32>(), h->cand.as<u32>() + static_cast<long long>(n_frames) * p.frame_cand_cap,
-               h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>());
+    {
+        // levels whose node arrays fit in LDS in one launch (LDS sized for the largest of them), the others
+        // (quotas beyond about 1130 keypoints per level) in a launch that keeps them in a global workspace
+        const int first_lds = quadtree_first_lds_level(p);
+        u32* cand_xy = h->cand.as<u32>();
+        u32* cand_node = h->cand.as<u32>() + static_cast<long long>(n_frames) * p.frame_cand_cap;
+        if (first_lds > 0) {
+            int ncap = 0;
+            for (int l = 0; l < first_lds; ++l) {
+                ncap = std::max(ncap, p.lv[l].ncap);
+            }
+            const size_t lds = static_cast<size_t>(p.max_cells + 1) * 4 + (16 + 8) * 4;
+            OVS_LAUNCH("k_quadtree", k_quadtree<false>, dim3(n_frames, first_lds), dim3(kQtThreads), lds, stream,
+                       p, h->slots.as<u32>(), h->cell_counts.as<u32>(), cand_xy, cand_node,
+                       h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(), 0, ncap, h->qt_ws.as<u32>());
+        }
+        if (first_lds < p.num_levels) {
+            int ncap = 0;
+            for (int l = first_lds; l < p.num_levels; ++l) {
+                ncap = std::max(ncap, p.lv[l].ncap);
+            }
+            OVS_LAUNCH("k_quadtree", k_quadtree<true>, dim3(n_frames, p.num_levels - first_lds), dim3(kQtThreads), quadtree_lds_bytes(p, ncap), stream,
+                       p, h->slots.as<u32>(), h->cell_counts.as<u32>(), cand_xy, cand_node,
+                       h->lvl_xy.as<u32>(), h->lvl_resp.as<uint8_t>(), h->lvl_count.as<int>(), first_lds, ncap, static_cast<u32*>(nullptr));
+        }
+    }
     if (forked) {
         OVS_HIP(hipStreamWaitEvent(stream, h->ev_join, 0));
     }

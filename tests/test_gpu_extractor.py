@@ -69,6 +69,71 @@ def test_blur_borders_every_width_class(w):
         assert np.array_equal(ext.blurred_level(lvl), rb), "blurred level %d differs at width %d" % (lvl, w)
 
 
+@pytest.mark.parametrize("levels,n,w,h", [(1, 3000, 1241, 376), (2, 2500, 640, 480), (8, 8000, 1241, 376),
+                                          # example/tum_rgbd/TUM_RGBD_rgbd_4.yaml:33 (10000 keypoints at 640x480), which
+                                          # is also the doubled initialiser quota of TUM_RGBD_mono_1.yaml:32
+                                          # (2 x 5000, tracking_module.cc:29-36)
+                                          (8, 10000, 640, 480)])
+def test_extract_large_quota_per_level(levels, n, w, h):
+    # per-level quotas beyond what the quadtree's node arrays hold in LDS (about 1130 keypoints): those
+    # levels run the kernel instance that keeps the arrays in a global workspace; with eight levels and
+    # 8000 keypoints the first three levels take that path and the rest the LDS one
+    rng = np.random.default_rng(levels * 100 + n)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    gk, _ = _compare(img, max_num_keypts=n, num_levels=levels)
+    assert len(gk) >= n // 2
+
+
+def test_extract_large_quota_doubled_by_the_initialiser():
+    # tracking_module.cc:29-36 builds the initialisation extractor with twice the configured keypoints:
+    # one handle at 5000, a second at 2 x 5000, the same frame through both, then the quota changed on
+    # a live handle (orb_extractor.cc:150-153 re-initialises)
+    img = synth.make_frame(640, 480, seed=4242)
+    _compare(img, max_num_keypts=5000)
+    _compare(img, max_num_keypts=10000)
+    ext = orb_extractor(orb_params(max_num_keypts=1000))
+    ext.extract(img)
+    ext.set_max_num_keypoints(10000)
+    gk, gd = ext.extract(img)
+    rk, rd = oracle.OrbExtractor(max_num_keypts=10000).extract(img)
+    assert np.array_equal(gk.view(np.uint8), rk.view(np.uint8)) and np.array_equal(gd, rd)
+
+
+def test_extract_large_quota_batch():
+    # every (level, frame) workgroup of the workspace instance owns one slice of the node workspace
+    import torch
+    from openvslam_amd import _abi as A
+    dev = torch.device("cuda", 0)
+    w, h, n_frames, n_kp = 640, 480, 5, 10000
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (n_frames, h, w), dtype=np.uint8)
+    frames[3] = synth.make_frame(w, h, seed=9)
+    ext = orb_extractor(orb_params(max_num_keypts=n_kp), device=0)
+    cap = ext.keypoint_capacity(w, h)
+    kps = torch.zeros((n_frames, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((n_frames, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros((n_frames,), dtype=torch.int32, device=dev)
+    d_frames = torch.from_numpy(frames).to(dev)
+    ext.extract_batch_dev(d_frames.data_ptr(), n_frames, w, h, w, w * h, kps.data_ptr(), desc.data_ptr(), counts.data_ptr(), cap,
+                          torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    h_counts = counts.cpu().numpy()
+    h_kps = kps.cpu().numpy().view(np.uint8).reshape(n_frames, cap, 28)
+    h_desc = desc.cpu().numpy()
+    ref = oracle.OrbExtractor(max_num_keypts=n_kp)
+    for f in range(n_frames):
+        k, d = ref.extract(frames[f])
+        assert h_counts[f] == len(k) > 1000
+        assert np.array_equal(h_kps[f, :len(k)].reshape(-1), k.view(np.uint8).reshape(-1)), "frame %d keypoints differ" % f
+        assert np.array_equal(h_desc[f, :len(k)], d), "frame %d descriptors differ" % f
+
+
+def test_extract_quota_beyond_the_limit_is_refused():
+    with pytest.raises(Exception):
+        ext = orb_extractor(orb_params(max_num_keypts=9000, num_levels=1))
+        ext.extract(np.zeros((480, 640), np.uint8))
+
+
 @pytest.mark.parametrize("kind", ["uniform", "salt_pepper", "checker"])
 def test_extract_dense_corner_images(kind):
     # images in which most pixels pass the FAST rejection test: the per-cell survivor list runs

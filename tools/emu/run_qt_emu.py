@@ -9,7 +9,8 @@ behaviour.
                   [--scale 1.2] [--image noise|synth|faint|sparse] [--seed 1] [--strict-lds] [--no-build]
 
 --hip      kernel source to cut the quadtree from (default: openvslam_amd/csrc/ovs_orb.hip)
---patched  the source has the NODES_LDS template parameter (the global-workspace experiment)
+--patched  the source has the NODES_LDS template parameter: levels whose node arrays do not fit in LDS run
+           the instance that keeps them in a global workspace (detected from the source when not given)
 """
 import argparse
 import os
@@ -44,6 +45,8 @@ def main():
     ap.add_argument("--strict-lds", action="store_true", help="a read past the LDS allocation is an error (the hardware returns 0)")
     a = ap.parse_args()
     w, h = (int(v) for v in a.size.split("x"))
+    with open(a.hip) as f:
+        a.patched = a.patched or "template <bool NODES_LDS>" in f.read()
     os.makedirs(a.work, exist_ok=True)
     here = os.path.dirname(os.path.abspath(__file__))
 
