@@ -87,8 +87,9 @@ typedef struct ovs_orb ovs_orb;
  * validation errors of orb_params.cc:14-24 come back as OVS_ERR_INVALID_ARGUMENT with the
  * reference's message.  `device` is the HIP device ordinal the handle lives on.
  * Limits (OVS_ERR_UNSUPPORTED from the first extract call, which plans for the image size): 16 levels,
- * 4134 pixels per side, and about 1130 keypoints per pyramid level (2 * quota + 8 quadtree nodes of
- * 72 bytes must fit in 160 KB of LDS). */
+ * 4134 pixels per side, and 8187 keypoints per pyramid level (about 37 000 keypoints at eight levels and
+ * scale 1.2; levels with more than about 1130 keep their quadtree node records in a device workspace of
+ * the handle instead of LDS: 72 bytes x (2 * quota + 8) per such level and frame of a batch). */
 int ovs_orb_create(const ovs_orb_params* params, int device, ovs_orb** out);
 void ovs_orb_destroy(ovs_orb* h);
 

@@ -40,16 +40,17 @@ def sharded_search(local_search, queries, dist=None, device=None, stream=None):
     initialised).  `local_search(queries)` searches this rank's shard and reports GLOBAL row numbers.
     Returns the merged result (KNN2 array), identical on every rank.
 
-    With a CUDA/HIP `device` the whole exchange stays on that device: `local_search` may return its
+    With a CUDA/HIP `device` the whole exchange stays on that device: `local_search` is called with
+    `stream` as torch's current stream and enqueues its search there (ovs_desc_db_search_dev on
+    torch.cuda.current_stream(device)); it may return its
     result as a uint8 tensor on the device (the output buffer of ovs_desc_db_search_dev), the
     per-shard lists travel in ONE RCCL all-gather and are merged by ovs_knn2_merge_dev.  Without a
     device (CPU tests, gloo) `local_search` returns a numpy array and the merge runs on the host."""
     import torch
-    local = local_search(queries)
     world = 1 if dist is None else dist.get_world_size()
     rec = np.dtype(A.KNN2_DTYPE).itemsize
     if device is None:
-        local = np.ascontiguousarray(local, dtype=A.KNN2_DTYPE)
+        local = np.ascontiguousarray(local_search(queries), dtype=A.KNN2_DTYPE)
         nq = len(local)
         if world == 1:
             return merge_topk_host(local, 1, nq)
@@ -58,15 +59,23 @@ def sharded_search(local_search, queries, dist=None, device=None, stream=None):
         dist.all_gather_into_tensor(recv, send)
         return merge_topk_host(recv.numpy().reshape(-1).view(A.KNN2_DTYPE).reshape(world, nq), world, nq)
     from ._lib import check, lib
-    if isinstance(local, torch.Tensor):
-        send = local.to(device).contiguous().view(torch.uint8).reshape(-1)
-    else:
-        send = torch.from_numpy(np.ascontiguousarray(local, dtype=A.KNN2_DTYPE).view(np.uint8).reshape(-1).copy()).to(device)
-    nq = send.numel() // rec
     with torch.cuda.device(device):
+        caller = torch.cuda.current_stream(device)
         if stream is None:
-            stream = torch.cuda.current_stream(device)
+            stream = caller
+        else:
+            # what the caller queued before this call (queries, database rows) is complete first
+            stream.wait_stream(caller)
+        # The local search runs with `stream` as the current stream, so that the all-gather and the merge,
+        # which are enqueued on `stream`, are ordered behind it.  A `local_search` that enqueues on another
+        # stream has to synchronise that stream before it returns.
         with torch.cuda.stream(stream):
+            local = local_search(queries)
+            if isinstance(local, torch.Tensor):
+                send = local.to(device).contiguous().view(torch.uint8).reshape(-1)
+            else:
+                send = torch.from_numpy(np.ascontiguousarray(local, dtype=A.KNN2_DTYPE).view(np.uint8).reshape(-1).copy()).to(device)
+            nq = send.numel() // rec
             if world > 1 or dist is not None:
                 recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=device)
                 dist.all_gather_into_tensor(recv, send)

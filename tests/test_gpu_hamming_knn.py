@@ -306,6 +306,12 @@ def test_sharded_search_device_path_over_rccl_world_of_one():
         # host lists into the device path
         got2 = ovd.sharded_search(lambda _q: db_search(db, 777, q), q, dist=dist, device=dev)
         assert got2.tobytes() == want.tobytes()
+        # on a stream of the caller's that is not the current one: the local search is called with that
+        # stream current, so search, all-gather and merge are one ordered chain
+        side = torch.cuda.Stream(dev)
+        for _ in range(3):
+            got3 = ovd.sharded_search(local_search, q, dist=dist, device=dev, stream=side)
+            assert got3.tobytes() == want.tobytes()
     finally:
         if h:
             L.ovs_desc_db_destroy(h)
