@@ -426,6 +426,10 @@ void ovs_desc_db_destroy(ovs_desc_db* db);
 /* Replaces the contents with n_rows host descriptors (copied). global_row_offset is added to
  * every reported row index (shard base when the database is partitioned over processes). */
 int ovs_desc_db_upload(ovs_desc_db* db, const uint8_t* descs, int64_t n_rows, int64_t global_row_offset);
+/* Device memory the handle itself holds (uploaded rows, the partial-result buffer of ovs_desc_db_search_dev,
+ * staging of the host-buffer search); attached rows and the built-in scratch array are not the handle's.
+ * Bookkeeping only: no device call. */
+int ovs_desc_db_device_bytes(const ovs_desc_db* db, int64_t* bytes);
 /* Adopts a device buffer the caller keeps alive (no copy). */
 int ovs_desc_db_attach_dev(ovs_desc_db* db, const uint8_t* d_descs, int64_t n_rows, int64_t global_row_offset);
 
@@ -446,8 +450,9 @@ int ovs_desc_db_search_dev(ovs_desc_db* db, const uint8_t* d_queries, int nq, ov
  * arguments and results as ovs_desc_db_search_dev; the per-slice partial results live in a 4 MiB array
  * that is part of the library's code object (one copy per GPU, held until the process ends) instead of
  * a buffer the call would have to grow.  A search whose slices x nq x 16 bytes exceed 4 MiB returns
- * OVS_ERR_CAPACITY: that cannot happen with 128 queries or more (matrix-core kernel, at most 196 608
- * partial entries); with fewer queries (popcount kernel, one slice per 4096 rows) it happens when
+ * OVS_ERR_CAPACITY: with 128 to 262 144 queries (matrix-core kernel, at most 196 608 partial entries while
+ * the rows are cut into more than one slice) that does not happen; beyond 262 144 queries one slice alone
+ * exceeds it; with fewer than 128 queries (popcount kernel, one slice per 4096 rows) it happens when
  * ceil(rows / 4096) x nq exceeds 262 144.  The call makes no hipMalloc / hipFree; the array's address is
  * looked up when the database handle is created.  All calls on one GPU share the array: calls that
  * overlap on one GPU (different streams or threads) race on it. */
@@ -493,8 +498,9 @@ int ovs_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_querie
  *   prev_matched_pts            n1 x 2 floats, in/out: search centres, updated for matched keypoints
  *   matched_indices_2_in_frm_1  out, n1 ints (-1 = none);  *num_matches = the return value
  * Window queries, Hamming distances and the overwrite rule of area.cc:46-49,75-85 (a later keypoint
- * takes over a candidate it is strictly closer to) run on the device; frm_2 may hold at most about
- * 18 000 keypoints (its per-keypoint state lives in LDS), more give OVS_ERR_UNSUPPORTED. */
+ * takes over a candidate it is strictly closer to) run on the device.  Up to about 18 000 keypoints in
+ * frm_2 the per-keypoint state of that rule lives in LDS; beyond that it lives in device memory and the
+ * queries are resolved one per round (slower, same result).  n1 and frm_2->num_keypts < 2^20. */
 int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint8_t* descs_1, int n1,
                                  const ovs_frame_view* frm_2, float* prev_matched_pts, int margin,
                                  float lowe_ratio, int check_orientation,

@@ -10,6 +10,9 @@ from . import _abi as A
 
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libovs_hip.so"
 
+# status codes of include/ovs.h
+OVS_OK, OVS_ERR_INVALID_ARGUMENT, OVS_ERR_CAPACITY, OVS_ERR_HIP, OVS_ERR_UNSUPPORTED, OVS_ERR_OUT_OF_RANGE = 0, -1, -2, -3, -4, -5
+
 _lib = None
 
 
@@ -127,6 +130,7 @@ def _declare(L):
     L.ovs_desc_db_destroy.restype = None
     L.ovs_desc_db_upload.argtypes = [vp, A.u8p, C.c_int64, C.c_int64]
     L.ovs_desc_db_attach_dev.argtypes = [vp, vp, C.c_int64, C.c_int64]
+    L.ovs_desc_db_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.ovs_desc_db_search.argtypes = [vp, A.u8p, i, A.knn2p]
     L.ovs_desc_db_search_dev.argtypes = [vp, vp, i, vp, vp]
     L.ovs_desc_db_search_noalloc_dev.argtypes = [vp, vp, i, vp, vp]

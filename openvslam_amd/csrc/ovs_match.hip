@@ -623,6 +623,14 @@ void ovs_desc_db_destroy(ovs_desc_db* db) {
     delete db;
 }
 
+int ovs_desc_db_device_bytes(const ovs_desc_db* db, int64_t* bytes) {
+    if (!db || !bytes) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "null argument");
+    }
+    *bytes = static_cast<int64_t>(db->own.bytes + db->partial.bytes + db->st_q.bytes + db->st_out.bytes);
+    return OVS_OK;
+}
+
 int ovs_desc_db_upload(ovs_desc_db* db, const uint8_t* descs, int64_t n_rows, int64_t global_row_offset) {
     if (!db || n_rows < 0 || (n_rows > 0 && !descs)) {
         return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");

@@ -2709,6 +2709,10 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
     if (row_stride < static_cast<size_t>(width)) {
         return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "row stride smaller than the width");
     }
+    if (row_stride >= (1u << 23) || static_cast<unsigned long long>(height - 1) * row_stride + static_cast<unsigned long long>(width) > (1ull << 31)) {
+        // the blur and descriptor kernels form row offsets inside a frame with 24-bit / 32-bit products
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "row stride of 2^23 bytes or more, or a frame that spans more than 2^31 bytes, is not supported");
+    }
     ovs::device_guard guard(h->device);
     if (!guard.ok) {
         return ovs::fail(OVS_ERR_HIP, "cannot select the handle's device");

@@ -800,8 +800,10 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
 
     constexpr bool AREA = MODE == kModeArea;
     // kArea: `state` holds, per keypoint of the searched frame, distance << 20 | query of the match that
-    // currently owns it (all ones = free); it takes the place of the claim bitmap
-    u32* state = reinterpret_cast<u32*>(lmatched);
+    // currently owns it (all ones = free); it takes the place of the claim bitmap.  Frames too large for
+    // the LDS plan keep it in the global `matched` array (initialised to -1 above, i.e. free) and resolve
+    // one query per round.
+    u32* state = IN_LDS ? reinterpret_cast<u32*>(lmatched) : reinterpret_cast<u32*>(P.matched);
     const bool excl = !kind_is_one_way(pp.kind);
     const int needed = (pp.kind == kFrameLms || pp.kind == kRange || pp.kind == kArea) ? 2 : 1;
     const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr
@@ -1376,10 +1378,11 @@ int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const 
         return launch_resolve_t<kModeTri>(d_prob, n_problems, max_n, pp, st);
     }
     if (pp.kind == kArea) {
-        // the (distance, owner) state of every keypoint of the searched frame has to fit in LDS
+        // the (distance, owner) state of every keypoint of the searched frame lives in LDS when it fits
+        // (about 18 000 keypoints), else in global memory with one query resolved per round
         const int lds_n = resolve_lds_n(max_n);
         if (lds_n == 0) {
-            return ovs::fail(OVS_ERR_UNSUPPORTED, "match::area: too many keypoints in the searched frame");
+            return launch_resolve_instance(k_proj_resolve<false, kModeArea, kArea>, d_prob, n_problems, resolve_lds_bytes(max_n, 0), 0, pp, st);
         }
         return launch_resolve_instance(k_proj_resolve<true, kModeArea, kArea>, d_prob, n_problems, resolve_lds_bytes(max_n, lds_n), lds_n, pp, st);
     }
@@ -2437,6 +2440,10 @@ int ovs_match_in_consistent_area(const ovs_keypoint* undist_keypts_1, const uint
     // the distances and the sequential take-over rule run on the device.
     if (n1 < 0 || !frm_2 || !num_matches || (n1 > 0 && (!undist_keypts_1 || !descs_1 || !prev_matched_pts || !matched_indices_2_in_frm_1))) {
         return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "invalid argument");
+    }
+    if (n1 >= (1 << 20)) {
+        // the take-over state packs distance << 20 | index of the owning keypoint of frame 1
+        return ovs::fail(OVS_ERR_UNSUPPORTED, "match::area: more than 2^20 keypoints in frame 1 are not supported");
     }
     std::vector<int32_t> sl(n1);
     std::vector<float> ang(n1);

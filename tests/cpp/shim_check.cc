@@ -2,7 +2,10 @@
 // the member names of data::frame, a landmark, a 4x4 pose with block<>(), an 8-bit matrix) and
 // links it with libovs_hip.so.  Without a GPU the program only checks that construction fails
 // with the library's "no HIP device" error; with a GPU (argv[1] == "run") it extracts two frames
-// and runs the matchers, printing counts for the Python side to compare.
+// and runs the matchers, printing counts for the Python side to compare.  argv[1] == "threads" runs the
+// extractors and matchers from four std::threads at once, the way the reference's tracking, mapping and
+// global optimisation threads and the two extraction threads of a stereo frame do (system.cc:126-127,
+// data/frame.cc:64-67), and compares every result with the one the same call gave on one thread.
 #include "ovs_shim.hpp"
 
 #include <array>
@@ -12,6 +15,8 @@
 #include <map>
 #include <memory>
 #include <set>
+#include <atomic>
+#include <thread>
 
 namespace mock {
 
@@ -208,9 +213,84 @@ static void make_image(mock::mat_u8& img, int w, int h, int shift) {
     for (int y = 0; y < h; ++y) std::memcpy(img.data + static_cast<size_t>(y) * w, canvas.data() + static_cast<size_t>(y) * (w + 64) + shift, w);
 }
 
+// Four threads, 20 rounds each, all released together: two extractors on two images, the projection matcher,
+// brute force + BoW matching.  Each matcher thread works on its own copies of the frames (the matchers write
+// landmarks_), as each of the reference's threads works on its own frame / keyframe objects.
+static int run_threads(ovs_shim::feature::orb_extractor& ext_l, const ovs_shim::feature::orb_params& prm, const mock::frame (&frm)[2],
+                       mock::mat_u8 (&img)[2]) {
+    using namespace ovs_shim;
+    feature::orb_extractor ext_r(prm);
+    mock::mat_u8 no_mask;
+    const int rounds = 20;
+    // one-thread results
+    mock::frame p1 = frm[1], p0 = frm[0];
+    const unsigned want_proj = match::projection(0.9f, true).match_current_and_last_frames(p1, p0, 15.0f);
+    const std::vector<mock::landmark*> want_lms = p1.landmarks_;
+    mock::frame b1 = frm[1], b0 = frm[0];
+    std::vector<std::pair<int, int>> want_pairs;
+    const unsigned want_bf = match::robust(0.75f, true).brute_force_match(b1, &b0, want_pairs);
+    for (unsigned i = 0; i < b0.num_keypts_; ++i) b0.bow_feat_vec_[3 + i % 40].push_back(i);
+    for (unsigned i = 0; i < b1.num_keypts_; ++i) { b1.bow_feat_vec_[3 + i % 40].push_back(i); b1.landmarks_[i] = frm[0].landmarks_[i % frm[0].num_keypts_]; }
+    std::vector<mock::landmark*> want_bow_matched;
+    const unsigned want_bow = match::bow_tree(0.75f, true).match_keyframes(&b0, &b1, want_bow_matched);
+
+    std::atomic<int> waiting(4), failures(0);
+    auto gate = [&]() { --waiting; while (waiting.load() > 0) std::this_thread::yield(); };
+    auto same_extraction = [](const std::vector<mock::keypoint>& k, const mock::mat_u8& d, const mock::frame& f) {
+        return k.size() == f.keypts_.size() && std::memcmp(k.data(), f.keypts_.data(), k.size() * sizeof(mock::keypoint)) == 0
+               && std::memcmp(d.data, f.descriptors_.data, 32 * k.size()) == 0;
+    };
+    auto extractor_thread = [&](feature::orb_extractor& ext, int which) {
+        try {
+            gate();
+            for (int r = 0; r < rounds; ++r) {
+                std::vector<mock::keypoint> k;
+                mock::mat_u8 d;
+                ext.extract(img[which], no_mask, k, d);
+                if (!same_extraction(k, d, frm[which])) ++failures;
+            }
+        }
+        catch (const std::exception& e) { std::printf("extractor thread %d: %s\n", which, e.what()); ++failures; }
+    };
+    std::thread t_left([&]() { extractor_thread(ext_l, 0); });
+    std::thread t_right([&]() { extractor_thread(ext_r, 1); });
+    std::thread t_proj([&]() {
+        try {
+            gate();
+            for (int r = 0; r < rounds; ++r) {
+                mock::frame c1 = frm[1], c0 = frm[0];
+                const unsigned n = match::projection(0.9f, true).match_current_and_last_frames(c1, c0, 15.0f);
+                if (n != want_proj || c1.landmarks_ != want_lms) ++failures;
+            }
+        }
+        catch (const std::exception& e) { std::printf("projection thread: %s\n", e.what()); ++failures; }
+    });
+    std::thread t_bf([&]() {
+        try {
+            gate();
+            for (int r = 0; r < rounds; ++r) {
+                std::vector<std::pair<int, int>> pairs;
+                mock::frame c1 = b1, c0 = b0;
+                c1.landmarks_ = frm[1].landmarks_; // brute force wants the frame without landmarks
+                const unsigned n = match::robust(0.75f, true).brute_force_match(c1, &c0, pairs);
+                if (n != want_bf || pairs != want_pairs) ++failures;
+                std::vector<mock::landmark*> matched;
+                const unsigned nb = match::bow_tree(0.75f, true).match_keyframes(&b0, &b1, matched);
+                if (nb != want_bow || matched != want_bow_matched) ++failures;
+            }
+        }
+        catch (const std::exception& e) { std::printf("brute force / bow thread: %s\n", e.what()); ++failures; }
+    });
+    t_left.join(); t_right.join(); t_proj.join(); t_bf.join();
+    std::printf("%s threads: 4 x %d rounds, projection %u brute_force %u bow %u, %d results differ from the one-thread run\n",
+                failures.load() == 0 ? "OK" : "FAIL", rounds, want_proj, want_bf, want_bow, failures.load());
+    return failures.load() == 0 && want_proj > 200 && want_bf > 100 && want_bow > 20 ? 0 : 3;
+}
+
 int main(int argc, char** argv) {
     using namespace ovs_shim;
-    const bool run = argc > 1 && std::string(argv[1]) == "run";
+    const bool threads = argc > 1 && std::string(argv[1]) == "threads";
+    const bool run = threads || (argc > 1 && std::string(argv[1]) == "run");
     if (!run) {
         try {
             feature::orb_extractor ext(feature::orb_params{});
@@ -258,6 +338,9 @@ int main(int argc, char** argv) {
         std::memcpy(lms.back()->desc.data, frm[0].descriptors_.data + 32 * static_cast<size_t>(i), 32);
         lms.back()->level = frm[0].keypts_[i].octave;
         frm[0].landmarks_[i] = lms.back().get();
+    }
+    if (threads) {
+        return run_threads(ext, prm, frm, img);
     }
     const unsigned n_proj = match::projection(0.9f, true).match_current_and_last_frames(frm[1], frm[0], 15.0f);
     unsigned written = 0;

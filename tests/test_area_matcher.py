@@ -124,3 +124,34 @@ def test_gpu_contested_keypoints(seed, n1, n2, check, lowe, margin):
     assert got_num == want_num and np.array_equal(got_m, want_m)
     assert got_prev.tobytes() == want_prev.tobytes()
     assert 0 < got_num <= n2
+
+
+@pytest.mark.gpu
+def test_gpu_searched_frame_beyond_the_lds_plan():
+    """More than about 18 000 keypoints in the searched frame: the take-over state of the resolve kernel
+    no longer fits in LDS and lives in global memory, one query resolved per round.  The reference has no
+    limit here (area.cc:8-112)."""
+    from openvslam_amd import match
+    rng = np.random.default_rng(9)
+    n2, n1 = 20000, 2500
+    k2 = np.zeros(n2, dtype=A.KEYPOINT_DTYPE)
+    k2["x"], k2["y"] = rng.uniform(5, 635, n2), rng.uniform(5, 475, n2)
+    k2["angle"] = rng.uniform(0, 360, n2)
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    src = rng.integers(0, 400, n1)  # many queries per target: matches change hands
+    d1 = d2[src].copy()
+    for i in range(n1):
+        for b in rng.choice(256, rng.integers(0, 40), replace=False):
+            d1[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    k1 = np.zeros(n1, dtype=A.KEYPOINT_DTYPE)
+    k1["x"] = k2["x"][src] + rng.normal(0, 4, n1).astype(np.float32)
+    k1["y"] = k2["y"][src] + rng.normal(0, 4, n1).astype(np.float32)
+    k1["angle"] = (k2["angle"][src] + rng.normal(0, 20, n1)) % 360
+    view2 = A.make_frame_view(k2, d2, SF, A.make_grid(0.0, 0.0, 640.0, 480.0))
+    prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32))
+    want_num, want_m, want_prev = oracle_area(k1, d1, view2, prev, 20, 0.9, 1)
+    got_prev = prev.copy()
+    got_num, got_m = match.area(0.9, True).match_in_consistent_area(k1, d1, view2, got_prev, 20)
+    assert got_num == want_num and np.array_equal(got_m, want_m)
+    assert got_prev.tobytes() == want_prev.tobytes()
+    assert 100 < got_num <= 400

@@ -13,7 +13,7 @@ ROOT = Path(__file__).resolve().parent.parent
 def build(tmp_path):
     exe = tmp_path / "shim_check"
     lib = ROOT / "openvslam_amd" / "lib"
-    subprocess.run(["g++", "-std=c++14", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), "-I", str(ROOT / "openvslam_amd" / "cpp"),
+    subprocess.run(["g++", "-std=c++14", "-pthread", "-Wall", "-Wextra", "-Werror", "-I", str(ROOT / "include"), "-I", str(ROOT / "openvslam_amd" / "cpp"),
                     str(ROOT / "tests" / "cpp" / "shim_check.cc"), "-o", str(exe), "-L", str(lib), "-lovs_hip", "-Wl,-rpath," + str(lib)],
                    check=True)
     return exe
@@ -34,3 +34,12 @@ def test_shim_extract_and_match_on_gpu(tmp_path):
     r = subprocess.run([str(exe), "run"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("OK keypts")
+
+
+@pytest.mark.gpu
+def test_shim_from_four_threads_on_gpu(tmp_path):
+    # system.cc:126-127, data/frame.cc:64-67: extractors and matchers from several std::threads at once
+    exe = build(tmp_path)
+    r = subprocess.run([str(exe), "threads"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("OK threads")

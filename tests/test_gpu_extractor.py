@@ -280,3 +280,20 @@ def test_repeated_single_frame_calls_on_one_handle():
     ext.set_max_num_keypoints(500)
     for f in frames[:4]:
         check(ext, f, max_num_keypts=500, ini_fast_thr=35)
+
+
+def test_row_stride_beyond_the_kernels_offset_arithmetic_is_refused():
+    """Row offsets inside a frame are 24-bit x 24-bit / 32-bit products in the blur and descriptor kernels:
+    a stride of 2^23 bytes or a frame spanning more than 2^31 bytes is refused, not mis-addressed."""
+    import ctypes as C
+    import torch
+    from openvslam_amd import _lib
+    ext = orb_extractor(orb_params(max_num_keypts=500))
+    dev = torch.device("cuda", 0)
+    img = torch.zeros((64, 64), dtype=torch.uint8, device=dev)
+    out = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    L = _lib.lib()
+    for stride in (1 << 23, (1 << 31) // 479 + 1):
+        rc = L.ovs_orb_extract_batch_dev(ext._h, img.data_ptr(), 1, 640, 480, stride, stride * 480, None, 0, out.data_ptr(), out.data_ptr(),
+                                         out.data_ptr(), 16, None)
+        assert rc == _lib.OVS_ERR_UNSUPPORTED and b"stride" in L.ovs_last_error()

@@ -1,12 +1,15 @@
 """The database search entry point that allocates nothing (ovs_desc_db_search_noalloc_dev) against
 ovs_desc_db_search_dev: same results bit for bit, on two calls in a row, the second one smaller (the
-built-in scratch array keeps the first call's contents), and a refusal beyond its capacity."""
+built-in scratch array keeps the first call's contents), a direct comparison with the oracle's scan, the
+property the entry point exists for (the handle holds no device memory after it, the device's free memory
+does not shrink across it), and a refusal beyond its capacity."""
 import ctypes as C
 
 import numpy as np
 import pytest
 import torch
 
+import oracle
 from openvslam_amd import _abi as A
 from openvslam_amd import _lib
 
@@ -31,7 +34,20 @@ def test_noalloc_search_equals_the_allocating_search():
     q_small = torch.from_numpy(rng.integers(0, 4, (40, 32), dtype=np.uint8)).to(dev)
     h = C.c_void_p()
     _lib.check(L.ovs_desc_db_create(0, C.byref(h)))
+    held = C.c_int64(-1)
     try:
+        # the entry point first, on a handle that has never searched: it must not grow the handle's
+        # partial-result buffer (or anything else) -- the handle holds no device memory afterwards, and the
+        # device has as much free memory as before the calls
+        _lib.check(L.ovs_desc_db_attach_dev(h, db_big.data_ptr(), db_big.shape[0], 0))
+        warm = _search(L.ovs_desc_db_search_noalloc_dev, h, q_big, q_big.shape[0], dev)  # code object, streams: set up
+        free_before = torch.cuda.mem_get_info(dev)[0]
+        for q in (q_big, q_small, q_big[:129]):
+            again = _search(L.ovs_desc_db_search_noalloc_dev, h, q, q.shape[0], dev)
+        assert torch.cuda.mem_get_info(dev)[0] >= free_before
+        _lib.check(L.ovs_desc_db_device_bytes(h, C.byref(held)))
+        assert held.value == 0
+        assert again.tobytes() == warm[:129].tobytes()
         # first call: matrix-core kernel, 2000 queries; second call: popcount kernel, 40 queries on a
         # smaller database, reading a prefix of the scratch memory the first call filled
         for db, q, offset in ((db_big, q_big, 1000), (db_small, q_small, 0), (db_big, q_big[:129], 5)):
@@ -40,6 +56,15 @@ def test_noalloc_search_equals_the_allocating_search():
             want = _search(L.ovs_desc_db_search_dev, h, q, q.shape[0], dev)
             assert got.tobytes() == want.tobytes()
             assert (got["row"][:, 0] >= offset).all()
+            if db is db_small:
+                # and directly against the oracle's strict-< scan (robust.cc:260-267)
+                h_db, h_q = db.cpu().numpy(), q.cpu().numpy()
+                ref = np.zeros(len(h_q), dtype=A.KNN2_DTYPE)
+                oracle.check(oracle.lib().ovo_knn2_search(A.ptr(h_db, A.u8p), len(h_db), offset, A.ptr(h_q, A.u8p), len(h_q), A.ptr(ref, A.knn2p)))
+                assert got.tobytes() == ref.tobytes()
+        # the allocating entry point did grow the handle
+        _lib.check(L.ovs_desc_db_device_bytes(h, C.byref(held)))
+        assert held.value > 0
         # beyond the capacity: 100 queries x 3000 slices of 4096 rows need 4.8 MB of partial results
         n_rows = 3000 * 4096
         huge = torch.zeros((n_rows, 32), dtype=torch.uint8, device=dev)
