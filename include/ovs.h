@@ -413,6 +413,83 @@ int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
                                 uint32_t* pairs, uint32_t* num_matches, int device);
 
 /* ------------------------------------------------------------------------------------------ */
+/* BoW transform: descriptors -> BowVector + FeatureVector                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* frame::compute_bow / keyframe::compute_bow (src/openvslam/data/frame.cc:162-170,
+ * data/keyframe.cc:181-189): bow_vocab_->transform(to_desc_vec(descriptors_), bow_vec_, bow_feat_vec_, 4)
+ * with the reference's default vocabulary type, DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>
+ * (data/bow_vocabulary.h:16).  DBoW2 itself (shinsumicco/DBoW2@687fcb7, Dockerfile.desktop:144) and the
+ * vocabulary file are not part of the reference tree: the vocabulary comes in as arrays (parsing the
+ * file stays with the caller), and the transform follows DBoW2's published algorithm:
+ *   per descriptor, from the root: among the children of the current node, in their stored order, the one
+ *   with the smallest Hamming distance wins (strict <: the first of equally distant children); repeat
+ *   until a node without children; its word id and weight are the result.  The node passed on the way at
+ *   level L - levelsup (root = level 0) is the descriptor's feature-vector node (the root when
+ *   L - levelsup <= 0; the leaf itself when the leaf lies above that level, where DBoW2 leaves the id
+ *   unset).  Words of weight <= 0 are dropped ("stopped").
+ *   BowVector: std::map<word id, value>; TF / TF_IDF add the weight once per descriptor in descriptor
+ *   order (value = ((w + w) + w) ..., in double), IDF / BINARY store it once; then the L1 / L2
+ *   normalisation of the scoring type, summed in ascending word order, or for DOT_PRODUCT with TF /
+ *   TF_IDF a division by the number of words.
+ *   FeatureVector: std::map<node id, std::vector<descriptor index>>, indices ascending.
+ * Values are IEEE doubles produced by the same operations in the same order as DBoW2's loops. */
+enum {
+    OVS_BOW_TF_IDF = 0, OVS_BOW_TF = 1, OVS_BOW_IDF = 2, OVS_BOW_BINARY = 3                  /* DBoW2::WeightingType */
+};
+enum {
+    OVS_BOW_L1_NORM = 0, OVS_BOW_L2_NORM = 1, OVS_BOW_CHI_SQUARE = 2, OVS_BOW_KL = 3,
+    OVS_BOW_BHATTACHARYYA = 4, OVS_BOW_DOT_PRODUCT = 5                                       /* DBoW2::ScoringType */
+};
+
+/* A DBoW2 vocabulary tree as arrays (m_nodes of TemplatedVocabulary): node 0 is the root; the children of
+ * node n are children[child_offsets[n] .. child_offsets[n + 1]) in the order of m_nodes[n].children; a node
+ * without children is a leaf (a word) and carries word_ids[n] and weights[n]. */
+typedef struct ovs_bow_vocab_view {
+    int32_t branching_factor;      /* m_k, informative */
+    int32_t depth_levels;          /* m_L */
+    int32_t weighting;             /* OVS_BOW_TF_IDF ... */
+    int32_t scoring;               /* OVS_BOW_L1_NORM ... */
+    int32_t num_nodes;             /* root included */
+    const uint8_t* node_descs;     /* num_nodes x 32 bytes (row 0, the root's, is not read) */
+    const uint32_t* child_offsets; /* num_nodes + 1, ascending */
+    const uint32_t* children;      /* child_offsets[num_nodes] node ids */
+    const uint32_t* word_ids;      /* num_nodes, read for leaves */
+    const double* weights;         /* num_nodes, read for leaves */
+} ovs_bow_vocab_view;
+
+typedef struct ovs_bow_vocab ovs_bow_vocab;
+
+/* Copies the tree to the device.  OVS_ERR_INVALID_ARGUMENT unless the arrays describe a tree rooted at
+ * node 0 in which every other node has exactly one parent. */
+int ovs_bow_vocab_create(const ovs_bow_vocab_view* view, int device, ovs_bow_vocab** out);
+void ovs_bow_vocab_destroy(ovs_bow_vocab* v);
+
+/* TemplatedVocabulary::transform(features, v, fv, levelsup) for n descriptors (host buffers).
+ *   word_of_feature / node_of_feature   out, n each, may be NULL: word id and feature-vector node of every
+ *                                       descriptor (word 0xFFFFFFFF for a stopped word)
+ *   bow_word_ids / bow_values           out, capacity n: the BowVector in ascending word order
+ *   fv_node_ids / fv_offsets / fv_indices   out, capacity n / n + 1 / n: the FeatureVector in the layout
+ *                                       of ovs_bow_feat_vec
+ * An empty vocabulary (the root has no children) gives empty outputs, as DBoW2 does. */
+int ovs_bow_transform(const ovs_bow_vocab* v, const uint8_t* descs, int n, int levelsup,
+                      uint32_t* word_of_feature, uint32_t* node_of_feature,
+                      uint32_t* bow_word_ids, double* bow_values, int32_t* num_words,
+                      uint32_t* fv_node_ids, uint32_t* fv_offsets, uint32_t* fv_indices, int32_t* fv_num_nodes);
+
+/* The same for n_frames descriptor sets on the device, frame f at d_descs + f * cap * 32 with d_counts[f]
+ * descriptors (the layout ovs_orb_extract_batch_dev writes; d_counts NULL: every frame has `cap`).  Outputs
+ * are per frame with strides cap (word / node of feature, BowVector, node ids, indices) and cap + 1
+ * (offsets); d_num_words / d_fv_num_nodes hold n_frames counts.  word_of_feature / node_of_feature may
+ * be NULL.  Enqueued on `stream`, not synchronised; descriptors 16-byte aligned. */
+int ovs_bow_transform_batch_dev(const ovs_bow_vocab* v, const uint8_t* d_descs, const int32_t* d_counts,
+                                int n_frames, int cap, int levelsup,
+                                uint32_t* d_word_of_feature, uint32_t* d_node_of_feature,
+                                uint32_t* d_bow_word_ids, double* d_bow_values, int32_t* d_num_words,
+                                uint32_t* d_fv_node_ids, uint32_t* d_fv_offsets, uint32_t* d_fv_indices,
+                                int32_t* d_fv_num_nodes, void* stream);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Keyframe-database brute-force search (relocalisation over a descriptor database)           */
 /* ------------------------------------------------------------------------------------------ */
 

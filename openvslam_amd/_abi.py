@@ -67,6 +67,16 @@ class BowFeatVec(C.Structure):
     _fields_ = [("num_nodes", C.c_int32), ("node_ids", u32p), ("offsets", u32p), ("indices", u32p)]
 
 
+class BowVocabView(C.Structure):
+    _fields_ = [("branching_factor", C.c_int32), ("depth_levels", C.c_int32), ("weighting", C.c_int32), ("scoring", C.c_int32),
+                ("num_nodes", C.c_int32), ("node_descs", u8p), ("child_offsets", u32p), ("children", u32p), ("word_ids", u32p),
+                ("weights", f64p)]
+
+
+BOW_TF_IDF, BOW_TF, BOW_IDF, BOW_BINARY = 0, 1, 2, 3
+BOW_L1_NORM, BOW_L2_NORM, BOW_CHI_SQUARE, BOW_KL, BOW_BHATTACHARYYA, BOW_DOT_PRODUCT = 0, 1, 2, 3, 4, 5
+
+
 class Knn2(C.Structure):
     _fields_ = [("dist", C.c_uint32 * 2), ("row", C.c_int64 * 2)]
 
@@ -167,6 +177,24 @@ def make_bow_feat_vec(node_to_indices):
     v.offsets = ptr(offsets, u32p)
     v.indices = ptr(indices, u32p)
     return Holder(v, node_ids, offsets, indices)
+
+
+def make_bow_vocab_view(k, L, node_descs, child_offsets, children, word_ids, weights, weighting=BOW_TF_IDF, scoring=BOW_L1_NORM):
+    """A DBoW2 vocabulary tree as arrays (node 0 = root, CSR children lists)."""
+    nd = np.ascontiguousarray(node_descs, dtype=np.uint8).reshape(-1, 32)
+    co = np.ascontiguousarray(child_offsets, dtype=np.uint32)
+    ch = np.ascontiguousarray(children, dtype=np.uint32)
+    wi = np.ascontiguousarray(word_ids, dtype=np.uint32)
+    we = np.ascontiguousarray(weights, dtype=np.float64)
+    v = BowVocabView()
+    v.branching_factor, v.depth_levels, v.weighting, v.scoring = k, L, weighting, scoring
+    v.num_nodes = len(co) - 1
+    v.node_descs = ptr(nd, u8p)
+    v.child_offsets = ptr(co, u32p)
+    v.children = ptr(ch, u32p)
+    v.word_ids = ptr(wi, u32p)
+    v.weights = ptr(we, f64p)
+    return Holder(v, nd, co, ch, wi, we)
 
 
 def make_orb_params(max_num_keypts=2000, scale_factor=1.2, num_levels=8, ini_fast_thr=20, min_fast_thr=7,

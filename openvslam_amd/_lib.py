@@ -122,6 +122,13 @@ def _declare(L):
     L.ovs_match_for_triangulation.argtypes = [bv, A.u8p, A.kpp, A.f64p, A.f32p, A.u8p, i,
                                               bv, A.u8p, A.kpp, A.f64p, A.f32p, A.u8p, i,
                                               A.f64p, A.f64p, A.f32p, i, i, A.u32p, A.u32p, i]
+    vv = C.POINTER(A.BowVocabView)
+    i32 = C.POINTER(C.c_int32)
+    L.ovs_bow_vocab_create.argtypes = [vv, i, C.POINTER(vp)]
+    L.ovs_bow_vocab_destroy.argtypes = [vp]
+    L.ovs_bow_vocab_destroy.restype = None
+    L.ovs_bow_transform.argtypes = [vp, A.u8p, i, i, A.u32p, A.u32p, A.u32p, A.f64p, i32, A.u32p, A.u32p, A.u32p, i32]
+    L.ovs_bow_transform_batch_dev.argtypes = [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ovs_match_in_consistent_area.argtypes = [A.kpp, A.u8p, i, fv, A.f32p, i, C.c_float, i, A.i32p, A.u32p, i]
     L.ovs_landmark_compute_descriptors.argtypes = [A.u8p, A.u32p, i, A.i32p, i]
     L.ovs_fuse_best_candidates.argtypes = [fv, pq, A.f64p, A.f32p, C.c_float, i, A.i32p, i]

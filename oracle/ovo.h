@@ -161,6 +161,11 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
                             const uint8_t* valid_2, int n2,
                             float lowe_ratio, int check_orientation,
                             int32_t* matched_idx2_in_kf1, uint32_t* num_matches);
+/* frame::compute_bow (src/openvslam/data/frame.cc:162-170): DBoW2 TemplatedVocabulary::transform(features, v, fv,
+ * levelsup), restated from the published algorithm (DBoW2 is not in the reference tree: parity unpinned) */
+int ovo_bow_transform(const ovs_bow_vocab_view* voc, const uint8_t* descs, int n, int levelsup, uint32_t* word_of_feature,
+                      uint32_t* node_of_feature, uint32_t* bow_word_ids, double* bow_values, int32_t* num_words,
+                      uint32_t* fv_node_ids, uint32_t* fv_offsets, uint32_t* fv_indices, int32_t* fv_num_nodes);
 /* candidate search of fuse::detect_duplication / replace_duplication (src/openvslam/match/fuse.cc) */
 int ovo_fuse_best_candidates(const ovs_frame_view* keyfrm, const ovs_proj_queries* q, const double* reproj_xy_d,
                              const float* inv_level_sigma_sq, float margin, int replace_mode, int32_t* best_idx_of_query);

@@ -105,6 +105,8 @@ def _declare(L):
     bv = C.POINTER(A.BowFeatVec)
     L.ovo_bow_match_frame_and_keyframe.argtypes = [bv, A.u8p, A.f32p, A.u8p, i, bv, A.u8p, A.f32p, i,
                                                    C.c_float, i, A.i32p, A.u32p]
+    L.ovo_bow_transform.argtypes = [C.POINTER(A.BowVocabView), A.u8p, i, i, A.u32p, A.u32p, A.u32p, A.f64p, C.POINTER(C.c_int32),
+                                    A.u32p, A.u32p, A.u32p, C.POINTER(C.c_int32)]
     L.ovo_bow_match_keyframes.argtypes = [bv, A.u8p, A.f32p, A.u8p, i, bv, A.u8p, A.f32p, A.u8p, i,
                                           C.c_float, i, A.i32p, A.u32p]
     L.ovo_match_for_triangulation.argtypes = [bv, A.u8p, A.kpp, A.f64p, A.f32p, A.u8p, i,
