@@ -1,6 +1,7 @@
 // ovs_shim.hpp -- header-only C++ layer with the class names and member signatures of
 // feature::orb_extractor (src/openvslam/feature/orb_extractor.h:18-78) and
-// match::{projection, robust, bow_tree, area, fuse, stereo} (src/openvslam/match/*.h) on top of the C ABI of
+// match::{projection, robust, bow_tree, area, fuse, stereo} (src/openvslam/match/*.h), plus the transform of
+// data::bow_vocabulary (src/openvslam/data/bow_vocabulary.h:16) that frame::compute_bow calls, on top of the C ABI of
 // include/ovs.h.  The classes are templates over the caller's frame / keyframe / landmark /
 // matrix types and only use the member names the reference's own implementation uses
 // (landmarks_, undist_keypts_, descriptors_, stereo_x_right_, scale_factors_, camera_, ...), so in
@@ -453,6 +454,72 @@ void undistort_keypoints_fisheye(const Camera& cam, const std::vector<KeyPoint>&
 }
 
 } // namespace camera
+
+namespace data {
+
+// data::bow_vocabulary (data/bow_vocabulary.h:16, the DBoW2 type) as frame::compute_bow and
+// keyframe::compute_bow use it (data/frame.cc:162-170, data/keyframe.cc:181-189):
+//     bow_vocab_->transform(util::converter::to_desc_vec(descriptors_), bow_vec_, bow_feat_vec_, 4);
+// The tree comes in as arrays (ovs_bow_vocab_view: what DBoW2 keeps in m_nodes, which a caller exports from
+// its vocabulary once, e.g. from the nodes of the file it loads); the arrays are copied to the device.
+// BowVector / FeatureVector are the caller's DBoW2 types: std::map<unsigned, double> and
+// std::map<unsigned, std::vector<unsigned>>.
+class bow_vocabulary {
+public:
+    explicit bow_vocabulary(const ovs_bow_vocab_view& view, int device = 0) { check(ovs_bow_vocab_create(&view, device, &h_)); }
+    ~bow_vocabulary() { ovs_bow_vocab_destroy(h_); }
+    bow_vocabulary(const bow_vocabulary&) = delete;
+    bow_vocabulary& operator=(const bow_vocabulary&) = delete;
+
+    // descriptors as the rows of one 8-bit matrix (frame::descriptors_); to_desc_vec only splits it into rows
+    template <class Mat, class BowVector, class FeatureVector>
+    void transform(const Mat& descriptors, BowVector& v, FeatureVector& fv, int levelsup) const {
+        typedef mat_traits<Mat> T;
+        const int n = T::empty(descriptors) ? 0 : T::rows(descriptors);
+        std::vector<uint8_t> packed(static_cast<size_t>(n) * 32);
+        for (int i = 0; i < n; ++i) {
+            std::memcpy(packed.data() + 32 * static_cast<size_t>(i), T::data(descriptors) + T::step(descriptors) * static_cast<size_t>(i), 32);
+        }
+        transform_rows(packed.data(), n, v, fv, levelsup);
+    }
+    // descriptors as util::converter::to_desc_vec returns them: one 1 x 32 matrix per keypoint
+    template <class Mat, class BowVector, class FeatureVector>
+    void transform(const std::vector<Mat>& features, BowVector& v, FeatureVector& fv, int levelsup) const {
+        typedef mat_traits<Mat> T;
+        std::vector<uint8_t> packed(features.size() * 32);
+        for (size_t i = 0; i < features.size(); ++i) {
+            std::memcpy(packed.data() + 32 * i, T::data(features[i]), 32);
+        }
+        transform_rows(packed.data(), static_cast<int>(features.size()), v, fv, levelsup);
+    }
+    ovs_bow_vocab* handle() const { return h_; }
+
+private:
+    template <class BowVector, class FeatureVector>
+    void transform_rows(const uint8_t* rows, int n, BowVector& v, FeatureVector& fv, int levelsup) const {
+        v.clear();
+        fv.clear();
+        if (n == 0) {
+            return;
+        }
+        const size_t nn = static_cast<size_t>(n);
+        std::vector<uint32_t> word_ids(nn), node_ids(nn), offsets(nn + 1), indices(nn);
+        std::vector<double> values(nn);
+        int32_t num_words = 0, num_nodes = 0;
+        check(ovs_bow_transform(h_, rows, n, levelsup, nullptr, nullptr, word_ids.data(), values.data(), &num_words, node_ids.data(), offsets.data(),
+                                indices.data(), &num_nodes));
+        for (int32_t k = 0; k < num_words; ++k) {
+            v.insert(v.end(), typename BowVector::value_type(word_ids[k], values[k]));
+        }
+        for (int32_t k = 0; k < num_nodes; ++k) {
+            typename FeatureVector::mapped_type idx(indices.begin() + offsets[k], indices.begin() + offsets[k + 1]);
+            fv.insert(fv.end(), typename FeatureVector::value_type(node_ids[k], std::move(idx)));
+        }
+    }
+    ovs_bow_vocab* h_ = nullptr;
+};
+
+} // namespace data
 
 namespace match {
 

@@ -360,6 +360,39 @@ int main(int argc, char** argv) {
     std::vector<mock::landmark*> bow_matched;
     for (unsigned i = 0; i < frm[1].num_keypts_; ++i) frm[1].landmarks_[i] = all_lms[i % all_lms.size()];
     const unsigned n_bow = match::bow_tree(0.75f, true).match_keyframes(&frm[0], &frm[1], bow_matched);
+    // data::bow_vocabulary::transform as frame::compute_bow calls it: a two-level binary tree whose four words
+    // split the descriptors by their first byte's top bits
+    bool bow_ok = false;
+    {
+        uint8_t nd[7][32];
+        std::memset(nd, 0, sizeof(nd));
+        std::memset(nd[2], 0xFF, 32);                      // children of the root: all zeros / all ones
+        nd[4][0] = 0xFF;                                   // leaves under node 1: node 3 all zeros, node 4 with the first byte set
+        std::memset(nd[5], 0xFF, 32); nd[5][0] = 0x00;     // leaves under node 2: node 5 with the first byte clear, node 6 all ones
+        std::memset(nd[6], 0xFF, 32);
+        const uint32_t child_offsets[8] = {0, 2, 4, 6, 6, 6, 6, 6}, children[6] = {1, 2, 3, 4, 5, 6}, word_ids[7] = {0, 0, 0, 0, 1, 2, 3};
+        const double weights[7] = {0, 0, 0, 1.0, 2.0, 3.0, 4.0};
+        ovs_bow_vocab_view view{};
+        view.branching_factor = 2; view.depth_levels = 2; view.weighting = OVS_BOW_TF_IDF; view.scoring = OVS_BOW_L1_NORM; view.num_nodes = 7;
+        view.node_descs = &nd[0][0]; view.child_offsets = child_offsets; view.children = children; view.word_ids = word_ids; view.weights = weights;
+        data::bow_vocabulary vocab(view);
+        std::map<unsigned, double> bow_vec;
+        std::map<unsigned, std::vector<unsigned>> feat_vec;
+        vocab.transform(frm[0].descriptors_, bow_vec, feat_vec, 1);
+        double sum = 0; size_t members = 0; bool ascending = true;
+        for (const auto& kv : bow_vec) sum += kv.second;
+        for (const auto& kv : feat_vec) {
+            members += kv.second.size();
+            for (size_t i = 1; i < kv.second.size(); ++i) ascending = ascending && kv.second[i - 1] < kv.second[i];
+        }
+        std::vector<mock::mat_u8> rows(frm[0].num_keypts_);
+        for (unsigned i = 0; i < frm[0].num_keypts_; ++i) { rows[i].create(1, 32); std::memcpy(rows[i].data, frm[0].descriptors_.data + 32 * static_cast<size_t>(i), 32); }
+        std::map<unsigned, double> bow_vec2;
+        std::map<unsigned, std::vector<unsigned>> feat_vec2;
+        vocab.transform(rows, bow_vec2, feat_vec2, 1);
+        bow_ok = bow_vec.size() >= 2 && bow_vec.size() <= 4 && std::fabs(sum - 1.0) < 1e-12 && members == frm[0].num_keypts_ && ascending
+                 && feat_vec.size() == 2 && feat_vec.count(1) && feat_vec.count(2) && bow_vec2 == bow_vec && feat_vec2 == feat_vec;
+    }
     // image preparation: BGR -> gray of a colour copy of frame 0 (equal channels stay), identity
     // rectification, histogram stretch
     mock::mat_u8 bgr;
@@ -490,12 +523,12 @@ int main(int argc, char** argv) {
     for (auto& lm : lms2) replaced += lm->erased;
     for (auto& lm : lms) { replaced += lm->erased; adopted += lm->is_observed_in_keyframe(&frm[1]); }
     std::printf("OK keypts %u %u projection %u written %u brute_force %u pairs %zu frame_and_keyframe %u sim3 %u bow_keyframes %u "
-                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d bearings %d stereo %u/%u\n",
+                "robust_keyframe %u triangulation %u area %u mutual %u fuse_detect %u fuse_replace %u replaced %u adopted %u preparation %d bearings %d bow %d stereo %u/%u\n",
                 frm[0].num_keypts_, frm[1].num_keypts_, n_proj, written, n_bf, pairs.size(), n_kf, n_sim3, n_bow, n_rkf, n_tri, n_area, n_mutual,
-                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0, bearings_ok ? 1 : 0, n_stereo_ok, n_stereo);
+                n_detect, n_replace, replaced, adopted, pre_ok ? 1 : 0, bearings_ok ? 1 : 0, bow_ok ? 1 : 0, n_stereo_ok, n_stereo);
     const bool ok = n_proj == written && n_proj > 200 && n_bf == pairs.size() && n_bf > 100 && n_kf > 200 && n_sim3 > 100 && n_bow > 100
                     && n_rkf > 50 && n_rkf <= n_bf && n_tri == tri_pairs.size() && n_tri > 50 && n_area > 50 && area_moved == n_area
                     && n_mutual == mutual_written && n_mutual > 100 && n_detect == dup_written && n_detect > 100 && n_replace == replaced
-                    && n_replace > 100 && adopted > 50 && pre_ok && bearings_ok && stereo_ok;
+                    && n_replace > 100 && adopted > 50 && pre_ok && bearings_ok && stereo_ok && bow_ok;
     return ok ? 0 : 2;
 }
