@@ -115,6 +115,22 @@ def rank_env(args):
     return world, rank, local_rank
 
 
+def planned_legs(args, world):
+    """The objects rank 0's JSON line carries next to the timed value, as a function of the flags alone (the
+    world size does not change them: rank 0 runs the extra legs by itself after the timed region)."""
+    legs = ["roofline"]
+    if args.workload == "knn":
+        legs.append("parity")
+        if not args.no_cpu_baseline:
+            legs.append("cpu_baseline")
+        return legs
+    if not args.no_extras:
+        legs += ["pcie_inclusive", "latency_b1"]
+        if not args.no_cpu_baseline:
+            legs += ["cpu_baseline", "parity"]
+    return legs
+
+
 # ---- extract + match workloads -------------------------------------------------------------------------
 def level_pixels(cfg):
     """Pixels per pyramid level as orb_extractor.cc:267-268 sizes them (float scale chain)."""
@@ -332,7 +348,7 @@ def pmc_traffic(kernel):
     import csv
     files = sorted((ROOT / "profiles").glob("r*_pmc_per_kernel.csv"), key=lambda p: (len(p.name), p.name))
     if not files:
-        return None, None, None
+        return None, None, None, None
     per_kernel, total = None, 0.0
     with open(files[-1]) as f:
         rows = list(csv.DictReader(f))
@@ -345,7 +361,7 @@ def pmc_traffic(kernel):
         total += b * float(row["launches_seen"]) / sets
         if row["kernel"].split("<")[0] == kernel:
             per_kernel = b
-    return per_kernel, total, files[-1].name
+    return per_kernel, total, files[-1].name, rows[0].get("csrc_sha256")
 
 
 def stream_copy_gbs(dev):
@@ -364,55 +380,113 @@ def stream_copy_gbs(dev):
     return 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pcie_inclusive(cfg, subs, frames, per, steps, dev):
-    """The same step fed from the host: frames in page-locked memory go up on a copy stream into one of
-    two device input buffers per sub-batch (double buffered: the upload of step s + 1 overlaps the
-    kernels of step s), the kernels run, keypoints / descriptors / counts / matches come down into
-    page-locked memory on the sub-batch's stream."""
+def pcie_inclusive(cfg, subs, frames, per, steps, dev, device_index):
+    """The same step fed from the host.  Up: frames in page-locked memory go into one of two device input
+    buffers per sub-batch on an upload stream (the upload of step s + 1 overlaps the kernels of step s).
+    Down: the results of a sub-batch are packed on the device (ovs_pack_batch_results_dev: offsets = prefix
+    sum of the keypoint counts, then dense keypoints / descriptors / matched indices), the offsets table
+    comes down first, and once the host knows the total the payload -- not the capacity -- follows on a
+    download stream of its own while the next step computes (results lag one step)."""
     import torch
+    from openvslam_amd import _lib
+    L = _lib.lib()
     host_frames = torch.empty(frames.shape, dtype=torch.uint8, pin_memory=True)
     host_frames.copy_(frames)
-    copy_stream = torch.cuda.Stream(dev)
+    up_stream, down_stream = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     state = []
+    nf = per + 1
     for k, sp in enumerate(subs):
-        src = host_frames[k * per:k * per + per + 1]
-        bufs = [torch.empty((per + 1,) + tuple(frames.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
-        outs = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (sp.kps, sp.desc, sp.counts, sp.matched, sp.num_matches)]
-        state.append({"src": src, "bufs": bufs, "outs": outs, "uploaded": [torch.cuda.Event(), torch.cuda.Event()],
-                      "consumed": [None, None]})
+        st = {"src": host_frames[k * per:k * per + nf],
+              "bufs": [torch.empty((nf,) + tuple(frames.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)],
+              "uploaded": [torch.cuda.Event(), torch.cuda.Event()], "consumed": [None, None],
+              "packed_ev": [torch.cuda.Event(), torch.cuda.Event()], "offsets_ev": [torch.cuda.Event(), torch.cuda.Event()],
+              "downloaded": [None, None], "pending": None}
+        for name, shape, dtype in (("offsets", (nf + 1,), torch.int32), ("kps", (nf * sp.cap, 7), torch.float32),
+                                   ("desc", (nf * sp.cap, 32), torch.uint8), ("matched", (nf * sp.cap,), torch.int32),
+                                   ("num", (nf,), torch.int32)):
+            st["d_" + name] = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
+            st["h_" + name] = [torch.empty(shape, dtype=dtype, pin_memory=True) for _ in range(2)]
+        state.append(st)
     up_bytes = sum(s["src"].numel() for s in state)
-    down_bytes = sum(sum(o.numel() * o.element_size() for o in s["outs"]) for s in state)
+    down_bytes = [0]
+
+    def download(st, b):
+        """Payload of the step whose results sit in packed buffer b (its offsets table is on its way)."""
+        st["offsets_ev"][b].synchronize()
+        total = int(st["h_offsets"][b][nf])
+        with torch.cuda.stream(down_stream):
+            for name in ("kps", "desc", "matched"):
+                st["h_" + name][b][:total].copy_(st["d_" + name][b][:total], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(down_stream)
+            st["downloaded"][b] = ev
+        down_bytes[0] += total * (28 + 32 + 4) + (nf + 1) * 4 + nf * 4
 
     def step(s_idx):
         b = s_idx & 1
-        for st in state:
-            with torch.cuda.stream(copy_stream):
+        with torch.cuda.stream(up_stream):
+            for st in state:
                 if st["consumed"][b] is not None:
-                    copy_stream.wait_event(st["consumed"][b])
+                    up_stream.wait_event(st["consumed"][b])
                 st["bufs"][b].copy_(st["src"], non_blocking=True)
-                st["uploaded"][b].record(copy_stream)
+                st["uploaded"][b].record(up_stream)
         for st, sp in zip(state, subs):
             with torch.cuda.stream(sp.stream):
                 sp.stream.wait_event(st["uploaded"][b])
+                if st["downloaded"][b] is not None:
+                    sp.stream.wait_event(st["downloaded"][b])  # the packed buffers of step s - 2 are on the host
                 sp._step(st["bufs"][b])
                 ev = torch.cuda.Event()
                 ev.record(sp.stream)
                 st["consumed"][b] = ev
-                for o, t in zip(st["outs"], (sp.kps, sp.desc, sp.counts, sp.matched, sp.num_matches)):
-                    o.copy_(t, non_blocking=True)
+                _lib.check(L.ovs_pack_batch_results_dev(sp.counts.data_ptr(), nf, sp.cap, sp.kps.data_ptr(), sp.desc.data_ptr(), sp.matched.data_ptr(),
+                                                        st["d_offsets"][b].data_ptr(), st["d_kps"][b].data_ptr(), st["d_desc"][b].data_ptr(),
+                                                        st["d_matched"][b].data_ptr(), device_index, sp.stream.cuda_stream))
+                st["d_num"][b].copy_(sp.num_matches, non_blocking=True)
+                st["packed_ev"][b].record(sp.stream)
+            with torch.cuda.stream(down_stream):
+                down_stream.wait_event(st["packed_ev"][b])
+                st["h_offsets"][b].copy_(st["d_offsets"][b], non_blocking=True)
+                st["h_num"][b].copy_(st["d_num"][b], non_blocking=True)
+                st["offsets_ev"][b].record(down_stream)
+        # the payload of the previous step, now that this step keeps the device busy
+        for st in state:
+            if st["pending"] is not None:
+                download(st, st["pending"])
+            st["pending"] = b
+
+    def flush():
+        for st in state:
+            if st["pending"] is not None:
+                download(st, st["pending"])
+                st["pending"] = None
+        torch.cuda.synchronize(dev)
 
     for s_idx in range(2):
         step(s_idx)
-    torch.cuda.synchronize(dev)
+    flush()
+    down_bytes[0] = 0
     t0 = time.perf_counter()
     for s_idx in range(steps):
         step(s_idx)
-    torch.cuda.synchronize(dev)
+    flush()
     dt = (time.perf_counter() - t0) / steps
     n = per * len(subs)
-    return {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "h2d_gbs": up_bytes / dt / 1e9, "d2h_gbs": down_bytes / dt / 1e9,
-            "h2d_bytes_per_frame": up_bytes / n, "d2h_bytes_per_frame": down_bytes / n,
-            "note": "frames from page-locked host memory (double-buffered uploads on a copy stream), all results back to page-locked host memory"}
+    # the packed results of the last step against the capacity-strided arrays they were packed from
+    ok = True
+    for st, sp in zip(state, subs):
+        b = (steps - 1) & 1
+        off = st["h_offsets"][b].numpy()
+        cnt = sp.counts.cpu().numpy()
+        ok = ok and bool((off[1:] - off[:-1] == cnt).all())
+        f = nf - 1
+        ok = ok and bool(torch.equal(st["h_desc"][b][off[f]:off[f + 1]], sp.desc[f, :cnt[f]].cpu()))
+        ok = ok and bool(torch.equal(st["h_matched"][b][off[f]:off[f + 1]], sp.matched[f, :cnt[f]].cpu()))
+        ok = ok and bool(torch.equal(st["h_kps"][b][off[f]:off[f + 1]].view(torch.int32), sp.kps[f, :cnt[f]].cpu().view(torch.int32)))
+    return {"value": n / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt, "h2d_gbs": up_bytes / dt / 1e9, "d2h_gbs": down_bytes[0] / steps / dt / 1e9,
+            "h2d_bytes_per_frame": up_bytes / n, "d2h_bytes_per_frame": down_bytes[0] / steps / n, "packed_results_equal_strided": ok,
+            "note": "frames from page-locked host memory (double-buffered uploads on an upload stream); results packed on the device "
+                    "(dense keypoints, descriptors, matched indices + offsets) and brought down on a download stream while the next step runs"}
 
 
 def latency_b1(cfg, frames_host):
@@ -555,9 +629,11 @@ def run_extract_match(args, cfg):
     alg_bytes_per_launch = sb[STAGE_OF_KERNEL.get(dominant, dominant)] * (per + 1) / max(launches[dominant], 1)
     avg_ms = per_step[dominant] / max(launches[dominant], 1)
     achieved = alg_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, path_traffic, traffic_file = (pmc_traffic(dominant) if cfg["name"] == "kitti" else (None, None, None))
+    traffic, path_traffic, traffic_file, traffic_fp = (pmc_traffic(dominant) if cfg["name"] == "kitti" else (None, None, None, None))
     out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                       # counters come from a committed profile: stale when the library was built from other sources
+                       "traffic_stale": (traffic_fp != _lib.source_fingerprint()) if traffic_file else None,
                        "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %d frames per launch)" % (traffic_file, per + 1)) if traffic_file else None,
                        "stream_copy_gbs": stream_copy_gbs(dev),
                        "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
@@ -567,21 +643,34 @@ def run_extract_match(args, cfg):
                        "path_frac": path_bytes * value / world / 1e9 / HBM_PEAK_GBS,
                        "kernel_ms_per_launch_set": per_step,
                        "timing_pass": "one sub-batch of %d frames alone on one stream" % (per + 1)}
-    if world == 1 and not args.no_extras:
-        out["pcie_inclusive"] = pcie_inclusive(cfg, subs, frames, per, max(3, min(args.steps, 10)), dev)
+    legs = planned_legs(args, world)
+    if "pcie_inclusive" in legs:
+        # Rank 0 alone, after the timed region (the other ranks have left): the host-fed rate, the latency of a
+        # single frame, the CPU oracle on a bounded sample and the parity gate.  At N > 1 the CPU sample is
+        # shorter, so that a scaling sweep stays within minutes.
+        out["pcie_inclusive"] = pcie_inclusive(cfg, subs, frames, per, max(3, min(args.steps, 10)), dev, local_rank)
         host_frames = frames.cpu().numpy()
         out["latency_b1"] = latency_b1(cfg, host_frames)
-        if not args.no_cpu_baseline:
-            # device results of the first frames, taken before anything else reuses the buffers
-            subs[0].step(frames[:per + 1])
+        if "cpu_baseline" in legs:
+            # device results of every sub-batch, taken after the legs above have reused the buffers
+            step_all()
             torch.cuda.synchronize(dev)
-            base, kept = cpu_baseline(cfg, host_frames, args.cpu_seconds, keep=args.parity_frames)
+            budget = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 6.0)
+            base, kept = cpu_baseline(cfg, host_frames, budget, keep=args.parity_frames)
             out["cpu_baseline"] = {"value": base["fps"], "unit": "frames/s", "cores": base["cores"], "kind": "port",
                                    "single_thread_value": base["single"],
                                    "single_thread_ms_per_frame": {k: round(v, 3) for k, v in base["stages"].items()},
                                    "sample": "%d frames of the same synthetic sequence in %d contiguous chunks of %d (one halo frame each), "
                                              "extract + match, one oracle thread per chunk" % (base["sample"], base["cores"], base["chunk"])}
-            out["parity"] = parity_gate(subs[0], kept)
+            # the first frames of EVERY sub-batch (each runs on its own stream and handle) against the oracle
+            gates = [parity_gate(subs[0], kept)]
+            for k in range(1, len(subs)):
+                res = [0]
+                kept_k = _cpu_chunk(cfg, host_frames, k * per, k * per + 2, time.perf_counter() + 60.0, res, 0, keep=2)
+                gates.append(parity_gate(subs[k], kept_k))
+            out["parity"] = {"frames": sum(g["frames"] for g in gates), "sub_batches": len(gates), "bit_exact": all(g["bit_exact"] for g in gates),
+                             "checked": gates[0]["checked"] + "; the first frames of every sub-batch (stream)",
+                             "mismatches": ["sub-batch %d %s" % (k, m) for k, g in enumerate(gates) for m in g["mismatches"]]}
     emit(out)
     if "parity" in out and not out["parity"]["bit_exact"]:
         sys.stderr.write("bench.py: PARITY FAILURE: %s\n" % "; ".join(out["parity"]["mismatches"]))
@@ -700,11 +789,11 @@ def run_knn(args):
                             "traffic": None, "database_gbs": n_rows * 32 / (search_ms * 1e-3) / 1e9 if search_ms else None,
                             "kernel_ms": rep},
                "parity": {"planted_neighbours_found": planted_ok, "same_result_on_every_rank": bool(same_everywhere.item())}}
-        if world == 1 and not args.no_cpu_baseline:
-            # CPU oracle on a bounded sample: the first queries against the first rows of the database
+        if "cpu_baseline" in planned_legs(args, world):
+            # CPU oracle on a bounded sample: the first queries against the first rows of this rank's shard
             sys.path.insert(0, str(ROOT / "tests"))
             import oracle
-            sample_q, sample_rows = 16, 4_000_000
+            sample_q, sample_rows = 16, min(4_000_000 if world == 1 else 1_500_000, n_rows)
             db_host = db[:sample_rows].cpu().numpy()
             ref_out = np.zeros(sample_q, dtype=A.KNN2_DTYPE)
             t0 = time.perf_counter()
@@ -753,7 +842,8 @@ def main():
     if args.dry_run:
         world, rank, local_rank = rank_env(args)
         sys.stderr.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world,
-                                     "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}) + "\n")
+                                     "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")),
+                                     "legs": planned_legs(args, world) if rank == 0 else []}) + "\n")
         return 0
     claim_stdout()
     if args.batch is None:

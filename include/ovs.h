@@ -742,6 +742,19 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
                                          int32_t* d_matched, uint32_t* d_num_matches,
                                          int device, void* stream);
 
+/* Dense results for the trip to the host.  The reference returns exactly sized containers (a
+ * std::vector<cv::KeyPoint> and a cv::Mat with one row per keypoint, feature/orb_extractor.cc:116-120;
+ * landmark vectors of num_keypts_ entries); the batch entry points above write frame f at slot f of
+ * capacity-strided arrays because the counts only exist on the device.  This call moves the first
+ * min(d_counts[f], cap) records of every frame to d_offsets[f] of dense arrays (d_offsets: n_frames + 1
+ * int32, the exclusive prefix sum of the counts, d_offsets[n_frames] = total), so that a download moves the
+ * payload and not the capacity.  Any of the three (source, destination) pairs may be NULL; the dense
+ * arrays need room for the total (n_frames x cap is always enough).  Enqueued on `stream`. */
+int ovs_pack_batch_results_dev(const int32_t* d_counts, int n_frames, int cap,
+                               const ovs_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_matched,
+                               int32_t* d_offsets, ovs_keypoint* d_packed_kps, uint8_t* d_packed_desc,
+                               int32_t* d_packed_matched, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,19 @@ class OvsError(RuntimeError):
         self.message = message
 
 
+def source_fingerprint():
+    """sha256 over the sources the library is built from (csrc/*.hip, csrc/*.h, include/ovs.h, in name
+    order): stored with counter profiles so that a profile taken from other kernels can be told apart."""
+    import hashlib
+    root = Path(__file__).resolve().parent
+    files = sorted((root / "csrc").glob("*.hip")) + sorted((root / "csrc").glob("*.h")) + [root.parent / "include" / "ovs.h"]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -122,6 +135,7 @@ def _declare(L):
     L.ovs_match_for_triangulation.argtypes = [bv, A.u8p, A.kpp, A.f64p, A.f32p, A.u8p, i,
                                               bv, A.u8p, A.kpp, A.f64p, A.f32p, A.u8p, i,
                                               A.f64p, A.f64p, A.f32p, i, i, A.u32p, A.u32p, i]
+    L.ovs_pack_batch_results_dev.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp, i, vp]
     vv = C.POINTER(A.BowVocabView)
     i32 = C.POINTER(C.c_int32)
     L.ovs_bow_vocab_create.argtypes = [vv, i, C.POINTER(vp)]

@@ -47,7 +47,7 @@ def test_oracle_mirrors_the_compute_entry_points():
     import oracle
     L = oracle.lib()
     not_compute = re.compile(r"ovs_(last_error|device_count|timing_|orb_params_default|orb_get_|orb_keypoint_capacity|orb_level_size"
-                             r"|desc_db_(create|destroy|upload|attach_dev|device_bytes)|bow_vocab_|remap_(create|destroy)|map_)")
+                             r"|desc_db_(create|destroy|upload|attach_dev|device_bytes)|bow_vocab_|pack_batch_results|remap_(create|destroy)|map_)")
     renamed = {"ovs_orb_extract_batch_dev": "ovo_orb_extract", "ovs_orb_pyramid_level_dev": "ovo_orb_pyramid_level",
                "ovs_orb_download_pyramid_level": "ovo_orb_pyramid_level", "ovs_orb_download_blurred_level": "ovo_orb_blurred_level",
                "ovs_stereo_compute_dev": "ovo_stereo_compute", "ovs_stereo_compute_batch_dev": "ovo_stereo_compute", "ovs_stereo_compute_resident": "ovo_stereo_compute",

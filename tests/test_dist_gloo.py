@@ -94,6 +94,14 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert sorted(r["rank"] for r in ranks) == [0, 1, 2]
     assert all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in ranks)
     assert len({r["master"] for r in ranks}) == 1 and ranks[0]["master"].startswith("127.0.0.1:")
+    # rank 0's line carries the roofline, the CPU baseline, the parity gate and the host-fed legs at every
+    # world size, not only at one GPU
+    legs = {r["rank"]: r["legs"] for r in ranks}
+    assert set(legs[0]) >= {"roofline", "cpu_baseline", "parity", "pcie_inclusive", "latency_b1"} and legs[1] == legs[2] == []
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--workload", "knn", "--dry-run"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    knn = [json.loads(line) for line in p.stderr.splitlines() if line.startswith("{")]
+    assert p.returncode == 0 and set([r for r in knn if r["rank"] == 0][0]["legs"]) >= {"roofline", "cpu_baseline", "parity"}
     # a contradiction between --gpus and the environment is an error, not a silent single-rank run
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=120)

@@ -211,3 +211,42 @@ def test_two_streams_in_flight_share_no_scratch():
                 g, r = g.view(torch.int32), r.view(torch.int32)
             assert torch.equal(g, r), "sub-batch %s: %s differ (%d elements)" % (which, name, int((g != r).sum()))
     assert int(ra[2][4][1:].min()) > 100
+
+
+def test_pack_batch_results_for_the_trip_to_the_host():
+    """ovs_pack_batch_results_dev: the first counts[f] records of every frame of capacity-strided arrays end
+    up at offsets[f] of dense arrays (the exactly sized containers the reference returns,
+    orb_extractor.cc:116-120); counts above the capacity are clamped, empty frames take no room, more frames
+    than the scan's workgroup has threads."""
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    n_frames, cap = 1500, 300
+    counts = rng.integers(0, cap + 1, n_frames).astype(np.int32)
+    counts[5], counts[6], counts[1499] = 0, cap + 50, cap
+    kps = rng.integers(0, 2 ** 31, (n_frames, cap, 7), dtype=np.int32)
+    desc = rng.integers(0, 256, (n_frames, cap, 32), dtype=np.uint8)
+    matched = rng.integers(-2, cap, (n_frames, cap), dtype=np.int32)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in (("counts", counts), ("kps", kps), ("desc", desc), ("matched", matched))}
+    off = torch.zeros(n_frames + 1, dtype=torch.int32, device=dev)
+    o_kps = torch.zeros((n_frames * cap, 7), dtype=torch.int32, device=dev)
+    o_desc = torch.zeros((n_frames * cap, 32), dtype=torch.uint8, device=dev)
+    o_matched = torch.zeros(n_frames * cap, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().ovs_pack_batch_results_dev(d["counts"].data_ptr(), n_frames, cap, d["kps"].data_ptr(), d["desc"].data_ptr(), d["matched"].data_ptr(),
+                                                     off.data_ptr(), o_kps.data_ptr(), o_desc.data_ptr(), o_matched.data_ptr(), 0,
+                                                     torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize(dev)
+    c = np.minimum(counts, cap)
+    want_off = np.concatenate([[0], np.cumsum(c)]).astype(np.int32)
+    assert np.array_equal(off.cpu().numpy(), want_off)
+    total = int(want_off[-1])
+    keep = np.arange(cap)[None, :] < c[:, None]
+    assert np.array_equal(o_kps.cpu().numpy()[:total], kps[keep])
+    assert np.array_equal(o_desc.cpu().numpy()[:total], desc[keep])
+    assert np.array_equal(o_matched.cpu().numpy()[:total], matched[keep])
+    # descriptors only
+    off2 = torch.zeros_like(off)
+    o_desc2 = torch.zeros_like(o_desc)
+    _lib.check(_lib.lib().ovs_pack_batch_results_dev(d["counts"].data_ptr(), n_frames, cap, None, d["desc"].data_ptr(), None, off2.data_ptr(), None,
+                                                     o_desc2.data_ptr(), None, 0, torch.cuda.current_stream(dev).cuda_stream))
+    torch.cuda.synchronize(dev)
+    assert torch.equal(off2, off) and torch.equal(o_desc2[:total], o_desc[:total])

@@ -4,11 +4,16 @@
   <out>/pmc_per_kernel.csv      (mean counter value per launch for every k_* kernel)
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; FETCH_SIZE additionally counts 64 B per
 128-B request on gfx950 for wide streaming reads and is doubled in the hbm_read_bytes column
-(uncalibrated for narrower accesses: an upper bound there)."""
+(uncalibrated for narrower accesses: an upper bound there).  The last column is the fingerprint of the
+library's sources (openvslam_amd._lib.source_fingerprint): bench.py marks the counters as stale when the
+library it runs was built from other sources."""
 import csv
 import sys
 from collections import defaultdict
 from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from openvslam_amd._lib import source_fingerprint  # noqa: E402
 
 
 def short(name):
@@ -53,14 +58,15 @@ def main():
     with open(out / "pmc_per_kernel.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "launches_seen", "vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "wg_size", "grid_size(last)"]
-                   + counters + ["hbm_read_bytes(=2*FETCH_SIZE*1024)", "hbm_write_bytes(=WRITE_SIZE*1024)"])
+                   + counters + ["hbm_read_bytes(=2*FETCH_SIZE*1024)", "hbm_write_bytes(=WRITE_SIZE*1024)", "csrc_sha256"])
+        fingerprint = source_fingerprint()  # the sources of the library these counters were taken from
         for n in sorted(acc):
             k = acc[n]
             launches = max(v[1] for v in k.values())
             vals = [("%.1f" % (k[c][0] / k[c][1])) if c in k and k[c][1] else "" for c in counters]
             rd = 2 * 1024 * k["FETCH_SIZE"][0] / k["FETCH_SIZE"][1] if "FETCH_SIZE" in k and k["FETCH_SIZE"][1] else ""
             wr = 1024 * k["WRITE_SIZE"][0] / k["WRITE_SIZE"][1] if "WRITE_SIZE" in k and k["WRITE_SIZE"][1] else ""
-            w.writerow([n, launches, *meta[n]] + vals + [rd, wr])
+            w.writerow([n, launches, *meta[n]] + vals + [rd, wr, fingerprint])
     print(open(out / "pmc_per_kernel.csv").read())
     if (out / "kernel_stats.csv").exists():
         print(open(out / "kernel_stats.csv").read())
