@@ -537,9 +537,12 @@ __device__ __forceinline__ bool tri_gate(const frame_dev& f, const query_ctx& c,
     return inlier;
 }
 
+// `min_key`: candidates whose selection key is smaller are left out (the continuation of a list whose
+// entries up to min_key - 1 have been used up).  `posted` / `qid` (the workgroup-wide resolve kernel): entries
+// on which a query with an index below qid has posted are left out as well.
 template <int G, int K, int MODE>
 __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* qd, const uint8_t* occupied,
-                            const u32* blocked, u32 (&top)[K], u32& total) {
+                            const u32* blocked, u32 (&top)[K], u32& total, u32 min_key = 0u, const u32* posted = nullptr, u32 qid = 0u) {
     const int gl = threadIdx.x & (G - 1);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -632,8 +635,9 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
                         // area.cc:46-49: a keypoint an earlier query holds at this distance or closer is skipped
                         keep = !blocked || (blocked[en.w] >> 20) > dist;
                     }
+                    u32 key = (dist << 20) | (MODE == kModeTri ? 0xFFFFFu - j : j);
+                    keep = keep && key >= min_key && !(posted && posted[j] < qid);
                     if (keep) {
-                        u32 key = (dist << 20) | (MODE == kModeTri ? 0xFFFFFu - j : j);
                         ++cnt;
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
@@ -1129,6 +1133,315 @@ __global__ __launch_bounds__(64) void k_proj_resolve(const proj_problem* __restr
     }
 }
 
+// ---- resolution by a whole workgroup, for the matchers without a ratio test ---------------------------
+// projection::match_current_and_last_frames, match_frame_and_keyframe and match_by_Sim3_transform accept a
+// query's best free candidate when its distance is below a threshold, and nothing else about the
+// candidates matters (projection.cc:161-186, :273-298, :367-405).  Walking the queries in order, each
+// taking the best candidate no earlier (blocking) query holds, is then a serial dictatorship, and its
+// outcome is the one assignment in which every query holds the first entry of its list that no query with
+// a smaller index holds.  That fixed point is reached without walking the queries in order: all queries
+// post their index on their current candidate (LDS atomicMin), a query that finds a smaller index there
+// moves on to its next candidate, until nobody moves.  The minimum posted on a keypoint only ever
+// decreases, so a rejection is final, and a round costs two barriers however many queries take part
+// (the single-wave kernel retires the queries up to the first conflict per round: about twelve).
+// Queries of landmarks without observations take a keypoint without holding it (projection.cc:164): they
+// are rejected like the others but post nothing; the keypoint's slot ends up with the last taker.
+// A query whose eight listed candidates are all rejected while its window holds more gets the next eight
+// from a rescan of the window by one wave (selection keys above the last listed one).
+constexpr int kWideThreads = 1024;
+constexpr int kWideQueries = 4;    // queries per thread
+constexpr int kWideQueue = 256;    // list continuations per batch
+constexpr int kWideMaxRounds = 1 << 20;
+// LDS of the kernel: per entry of the searched frame's grid (an entry is a keypoint) the smallest query index
+// posted on it, its keypoint index and its angle; per query its candidate list as eight words
+// `distance << 20 | entry` -- the selection keys of window_topk: they order the candidates as the reference's
+// scan does, name the keypoint and are the lower bound of a list's continuation.  The rounds touch LDS only.
+__host__ __device__ inline size_t wide_lds_bytes(int n, int nq) { return (3 * (size_t)max(n, 1) + (size_t)max(nq, 1) * kTopK) * 4; }
+
+// The rotation bins that angle_checker keeps (angle_checker.h:126-134: the first three of the bin indices
+// sorted by size, descending, with std::sort) as a bit mask, computed by the first wave of the workgroup.
+// A non-empty bin with three larger bins is out, one with at most three bins of its size or larger is in,
+// whatever the sort does with equal sizes; only when equal sizes straddle the third place does the order
+// std::sort leaves them in decide, and then the port of that sort runs.
+__device__ __forceinline__ u32 kept_rotation_bins(const u32* hist, u32* order, ovs_sort::sort_frame* sort_stack) {
+    const int lane = threadIdx.x & 63;
+    const u32 s = lane < 30 ? hist[lane] : 0u;
+    u32 greater = 0, at_least = 0;
+    for (int b = 0; b < 30; ++b) {
+        const u32 v = hist[b];
+        greater += v > s;
+        at_least += v >= s;
+    }
+    const bool ambiguous = lane < 30 && s > 0 && greater < 3 && at_least > 3;
+    if (__ballot(ambiguous)) {
+        if (lane == 0) {
+            ovs_sort::index_sort_by_size(hist, order, 30, sort_stack);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        return (1u << order[0]) | (1u << order[1]) | (1u << order[2]);
+    }
+    return (u32)__ballot(lane < 30 && s > 0 && greater < 3);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kWideThreads) void k_proj_resolve_wide(const proj_problem* __restrict__ problems, proj_params pp_arg, int lds_n) {
+    proj_params pp = pp_arg;
+    if (KIND >= 0) {
+        pp.kind = KIND;
+    }
+    extern __shared__ u32 wide_sm[];
+    __shared__ u32 hist[32];
+    __shared__ u32 order[32];
+    __shared__ ovs_sort::sort_frame sort_stack[ovs_sort::kSortStackEntries];
+    __shared__ u32 queue[kWideQueue];
+    __shared__ u32 n_queue;
+    __shared__ u32 moved_flag[3];
+    __shared__ u32 keep_mask;
+    __shared__ u32 red[kWideThreads / 64];
+    const proj_problem& P = problems[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.frm.n, nq = P.q.n;
+    const bool orient = pp.check_orientation && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm);
+    u32* holder = wide_sm;                                        // lds_n words
+    u32* entry_idx = wide_sm + lds_n;                             // keypoint index of an entry
+    float* entry_angle = reinterpret_cast<float*>(wide_sm + 2 * lds_n);
+    u32* rows = wide_sm + 3 * lds_n;                              // nq x kTopK
+    const u32 athr = pp.kind == kFrameKeyfrm ? pp.thr : (pp.kind == kSim3 ? kThrLow : kThrHigh);
+    const int n_entries = (int)P.frm.cell_start[P.frm.grid.num_cols * P.frm.grid.num_rows];
+    for (int i = tid; i < n; i += kWideThreads) {
+        holder[i] = 0xFFFFFFFFu;
+        P.matched[i] = -1;
+        if (i < n_entries) {
+            const u32 idx = P.frm.g_entry[i].w;
+            entry_idx[i] = idx;
+            entry_angle[i] = orient ? P.frm.kps[idx].angle : 0.0f;
+        }
+    }
+    // the lists as selection keys: list key = distance << 40 | entry << 20 | keypoint
+    for (int i = tid; i < nq * kTopK; i += kWideThreads) {
+        const u64 key = P.lists[i];
+        rows[i] = key == kNoKey ? kNoKey32 : (u32)(key >> 20);
+    }
+    if (tid < 32) {
+        hist[tid] = 0;
+    }
+    if (tid < 3) {
+        moved_flag[tid] = 0;
+    }
+    if (tid == 0) {
+        n_queue = 0;
+    }
+    // state of this thread's queries: the current candidate (kNoKey32: none left), its position in the list,
+    // the number of candidates from the start of the current list on
+    u32 cur[kWideQueries], rem[kWideQueries];
+    int ptr[kWideQueries];
+    float qangle[kWideQueries];
+    bool blocks[kWideQueries], live[kWideQueries];
+    int waiting[kWideQueries]; // 0: no, 1: wants its list continued, 2: queued for it
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        cur[k] = kNoKey32;
+        rem[k] = 0;
+        ptr[k] = 0;
+        qangle[k] = 0.0f;
+        blocks[k] = false;
+        waiting[k] = 0;
+        live[k] = false;
+        if (q < nq && P.q.valid[q]) {
+            rem[k] = P.totals[q];
+            live[k] = rem[k] != 0;
+            blocks[k] = (pp.kind == kFrameKeyfrm || pp.kind == kSim3) ? true : (P.q.has_obs ? P.q.has_obs[q] != 0 : true);
+            qangle[k] = orient ? P.q.angle[q] : 0.0f;
+        }
+    }
+    __syncthreads();
+    auto usable = [&](u32 key) { return (key != kNoKey32 && sel_dist(key) <= athr) ? key : kNoKey32; };
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const u32 q = (u32)(tid + k * kWideThreads);
+        if (live[k]) {
+            cur[k] = usable(rows[(size_t)q * kTopK]);
+            if (cur[k] != kNoKey32 && blocks[k]) {
+                atomicMin(&holder[sel_entry(cur[k])], q);
+            }
+        }
+    }
+    __syncthreads();
+
+    // A round: every query looks at the word of its candidate; one that finds a smaller index there moves on
+    // (skipping candidates that already carry a smaller index) and posts on its new candidate at once.  A post
+    // made during a round may or may not be seen by the checks of that round; it is seen by the next, and a
+    // round in which nobody moved made no post, so its checks saw the final words.
+    // A query whose list is used up while its window holds more waits, holding nothing, until the other
+    // queries have settled; then all waiting queries get the next candidates of their windows at once, one wave
+    // per query (a rescan costs about 7 us of dependent loads, whether for one query or for sixteen), and the
+    // rounds go on.  The order of these events does not matter: words only decrease, rejections are final.
+    for (int round = 0;; ++round) {
+        int moved = 0;
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            const u32 q = (u32)(tid + k * kWideThreads);
+            bool stepped = false;
+            while (waiting[k] == 0 && cur[k] != kNoKey32 && holder[sel_entry(cur[k])] < q) {
+                stepped = true;
+                ++ptr[k];
+                if (ptr[k] == kTopK) {
+                    // the list is used up: the window holds more only if it counted more than the list's length
+                    if (rem[k] > (u32)kTopK) {
+                        waiting[k] = 1;
+                    }
+                    cur[k] = kNoKey32;
+                    break;
+                }
+                cur[k] = usable(rows[(size_t)q * kTopK + ptr[k]]);
+            }
+            if (stepped && cur[k] != kNoKey32 && blocks[k]) {
+                atomicMin(&holder[sel_entry(cur[k])], q);
+            }
+            moved |= stepped ? 1 : 0;
+            if (waiting[k] == 1) {
+                const u32 slot = atomicAdd(&n_queue, 1u);
+                if (slot < (u32)kWideQueue) {
+                    queue[slot] = q;
+                    waiting[k] = 2;
+                } // else: after the next batch
+            }
+        }
+        if (moved) {
+            moved_flag[round % 3] = 1u;
+        }
+        if (tid == 0) {
+            moved_flag[(round + 1) % 3] = 0u; // last read two rounds ago
+        }
+        __syncthreads();
+        if (moved_flag[round % 3] != 0u) {
+            if (round >= kWideMaxRounds) {
+                if (tid == 0) {
+                    *P.err = OVS_ERR_OUT_OF_RANGE; // cannot happen: every round with a move uses up a candidate
+                }
+                break;
+            }
+            continue;
+        }
+        // everybody who is not waiting has settled
+        const int asked = (int)n_queue;
+        if (asked == 0) {
+            break;
+        }
+        const int queued = min(asked, kWideQueue);
+        for (int e = wave; e < queued; e += kWideThreads / 64) {
+            const int q = (int)queue[e];
+            const u32 last = rows[(size_t)q * kTopK + kTopK - 1];
+            query_ctx c;
+            make_query_ctx<kModePlain>(pp, P.frm, P.q, q, c);
+            u32 qd[8];
+            load_desc(P.q.desc + 32 * (size_t)q, qd);
+            u32 sel[kTopK];
+            u32 t;
+            // behind the last candidate the query has seen, without the entries that already carry a smaller index
+            window_topk<64, kTopK, kModePlain>(P.frm, c, qd, P.occupied, nullptr, sel, t, last + 1u, holder, (u32)q);
+            if (lane < kTopK) {
+                u32 v = sel[0];
+#pragma unroll
+                for (int k = 1; k < kTopK; ++k) {
+                    v = lane == k ? sel[k] : v;
+                }
+                rows[(size_t)q * kTopK + lane] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            n_queue = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            const u32 q = (u32)(tid + k * kWideThreads);
+            if (waiting[k] == 2) {
+                waiting[k] = 0;
+                rem[k] -= (u32)kTopK;
+                ptr[k] = 0;
+                cur[k] = usable(rows[(size_t)q * kTopK]);
+                if (cur[k] != kNoKey32 && blocks[k]) {
+                    atomicMin(&holder[sel_entry(cur[k])], q);
+                }
+            }
+        }
+        __syncthreads(); // the cleared counter and the new posts, before the next round
+    }
+
+    // every query now holds its final candidate
+    u32 mynum = 0;
+    int acc[kWideQueries], bin[kWideQueries];
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        acc[k] = -1;
+        bin[k] = 0;
+        if (cur[k] != kNoKey32) {
+            const u32 e = sel_entry(cur[k]);
+            acc[k] = (int)entry_idx[e];
+            atomicMax(&P.matched[acc[k]], q); // the last taker of a keypoint that nobody held
+            ++mynum;
+            if (orient) {
+                const float ca = entry_angle[e];
+                bin[k] = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qangle[k], ca) : __fsub_rn(ca, qangle[k]));
+                if (bin[k] < 0 || 30 <= bin[k]) {
+                    *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
+                    bin[k] = 0;
+                }
+                atomicAdd(&hist[bin[k]], 1u);
+            }
+        }
+    }
+    u32 removed = 0;
+    if (orient) {
+        // rotation consistency, match/angle_checker.h: keep the three fullest of 30 bins
+        __syncthreads();
+        if (wave == 0) {
+            const u32 mask = kept_rotation_bins(hist, order, sort_stack);
+            if (lane == 0) {
+                keep_mask = mask;
+            }
+        }
+        __syncthreads();
+        const u32 keep = keep_mask;
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            if (0 <= acc[k] && !((keep >> bin[k]) & 1u)) {
+                if (pp.per_query_output) {
+                    acc[k] = -1;
+                }
+                else {
+                    P.matched[acc[k]] = -2; // after every taker has posted (barriers above)
+                }
+                ++removed;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        if (q < nq) {
+            P.acc_idx[q] = acc[k];
+        }
+    }
+    const u32 kept = wave_sum_u32(mynum - removed);
+    if (lane == 0) {
+        red[wave] = kept;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 num = 0;
+        for (int w = 0; w < kWideThreads / 64; ++w) {
+            num += red[w];
+        }
+        *P.num_matches = num;
+    }
+}
+
 // ---- get_keypoints_in_cell ------------------------------------------------------------------------
 // One wavefront per query.  count_only: out_counts[q] = number of indices; otherwise the indices
 // are written in the reference's order at out_indices[offsets[q]..].
@@ -1370,7 +1683,51 @@ int launch_resolve_t(const proj_problem* d_prob, int n_problems, int max_n, cons
 
 bool kind_is_fuse(int kind) { return kind == kFuseDetect || kind == kFuseReplace; }
 
-int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, const proj_params& pp, hipStream_t st) {
+// The workgroup-wide resolve kernel serves the matchers without a ratio test when the per-keypoint words fit
+// in LDS and a thread gets at most kWideQueries queries -- for calls with a few problems, where a frame is
+// waited for: a batch of hundreds of frames fills the device with one wave per frame and takes 0.24 ms for
+// 255 frames, while sixteen mostly waiting waves per frame take 0.37 ms and hold a compute unit each
+// (the four-stream step went from 5.96 to 7.85 ms).  OVS_RESOLVE=wave / wide forces one of the two.
+constexpr int kWideMaxProblems = 8;
+bool wide_resolve_applies(const proj_params& pp, int n_problems, int max_n, int max_nq) {
+    static const int forced = [] {
+        const char* e = std::getenv("OVS_RESOLVE");
+        return !e ? 0 : (std::string(e) == "wave" ? 1 : (std::string(e) == "wide" ? 2 : 0));
+    }();
+    const bool few = forced == 2 || (forced == 0 && n_problems <= kWideMaxProblems);
+    return few && (pp.kind == kCurrLast || pp.kind == kFrameKeyfrm || pp.kind == kSim3) && max_nq <= kWideThreads * kWideQueries
+           && wide_lds_bytes(max_n, max_nq) <= 150 * 1024;
+}
+
+template <typename Kernel>
+int launch_resolve_wide(Kernel kernel, const proj_problem* d_prob, int n_problems, int max_n, int max_nq, const proj_params& pp, hipStream_t st) {
+    const size_t bytes = wide_lds_bytes(max_n, max_nq);
+    if (bytes > 48 * 1024) {
+        static std::mutex mu;
+        static std::set<std::pair<int, const void*>> granted;
+        int dev = 0;
+        OVS_HIP(hipGetDevice(&dev));
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!granted.count({dev, fn})) {
+            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            granted.insert({dev, fn});
+        }
+    }
+    OVS_LAUNCH("k_proj_resolve_wide", kernel, dim3(n_problems), dim3(kWideThreads), bytes, st, d_prob, pp, std::max(max_n, 1));
+    return OVS_OK;
+}
+
+int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, int max_nq, const proj_params& pp, hipStream_t st) {
+    if (wide_resolve_applies(pp, n_problems, max_n, max_nq)) {
+        if (pp.kind == kCurrLast) {
+            return launch_resolve_wide(k_proj_resolve_wide<kCurrLast>, d_prob, n_problems, max_n, max_nq, pp, st);
+        }
+        if (pp.kind == kFrameKeyfrm) {
+            return launch_resolve_wide(k_proj_resolve_wide<kFrameKeyfrm>, d_prob, n_problems, max_n, max_nq, pp, st);
+        }
+        return launch_resolve_wide(k_proj_resolve_wide<kSim3>, d_prob, n_problems, max_n, max_nq, pp, st);
+    }
     if (kind_is_fuse(pp.kind)) {
         return launch_resolve_t<kModeFuse>(d_prob, n_problems, max_n, pp, st);
     }
@@ -1617,7 +1974,7 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
         constexpr int QPB = 256 / kGroup;
         launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
     }
-    if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
+    if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st)) != OVS_OK) {
         return rc;
     }
     OVS_HIP(hipGetLastError());
@@ -1832,7 +2189,7 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
             constexpr int QPB = 256 / kGroup;
             launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
         }
-        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), pp, st)) != OVS_OK) {
+        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st)) != OVS_OK) {
             return rc;
         }
         OVS_HIP(hipGetLastError());
@@ -2542,7 +2899,7 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
     if (n_frames > 1) {
         constexpr int QPB = 256 / kGroup;
         launch_candidates(dim3((cap + QPB - 1) / QPB, n_frames - 1), d_prob, pp, st);
-        if ((rc = launch_resolve(d_prob, n_frames - 1, cap, pp, st)) != OVS_OK) {
+        if ((rc = launch_resolve(d_prob, n_frames - 1, cap, cap, pp, st)) != OVS_OK) {
             return rc;
         }
     }
