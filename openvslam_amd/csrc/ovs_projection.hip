@@ -33,6 +33,7 @@ using namespace ovsm;
 namespace {
 
 constexpr int kTopK = 8;
+constexpr int kGroupLive = 16; // lanes per query when a call has a few problems (OVS_GROUP_LIVE=8 keeps kGroup)
 constexpr int kGroup = 8; // lanes per query in k_proj_candidates (16: 0.29 ms, 8: 0.21 ms, 4: 0.46 ms per 255 x 2243 queries)
 
 enum proj_kind {
@@ -131,13 +132,14 @@ __device__ __forceinline__ bool cell_of(const ovs_grid& g, float x, float y, int
 // ITEMS_LDS: the keypoint indices in cell order (the array the sort works on) live in LDS behind the
 // counters instead of in global memory: the scatter, the per-cell ordering and the final gather are
 // chains of dependent accesses, and the workgroup is the only thing running for its frame.
-template <bool ITEMS_LDS>
-__global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
+// T threads: 256 for batches (one workgroup per frame, hundreds of frames), 1024 for a single frame that is waited for
+template <bool ITEMS_LDS, int T>
+__global__ __launch_bounds__(T) void k_grid_build(const ovs_keypoint* __restrict__ kps_all, const uint8_t* __restrict__ desc_all,
                                                     const int* __restrict__ counts, int fixed_n, int cap, ovs_grid g,
                                                     u32* __restrict__ cell_start_all, u32* __restrict__ items_all,
                                                     uint4* __restrict__ entry_all, uint4* __restrict__ gdesc_all) {
     extern __shared__ u32 sm[];
-    __shared__ u32 red[8];
+    __shared__ u32 red[T / 64];
     const int f = blockIdx.x;
     const int n = counts ? max(min(counts[f], cap), 0) : fixed_n;
     const int ncell = (int)(g.num_cols * g.num_rows);
@@ -152,11 +154,11 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
     u32* cur = sm + ncell + 1; // ncell
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int c = tid; c <= ncell; c += 256) {
+    for (int c = tid; c <= ncell; c += T) {
         cnt[c] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += T) {
         int cx, cy;
         if (cell_of(g, kps[i].x, kps[i].y, cx, cy)) {
             atomicAdd(&cnt[cx * g.num_rows + cy], 1u);
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
     }
     __syncthreads();
     {
-        const int per = (ncell + 1 + 255) / 256;
+        const int per = (ncell + 1 + T - 1) / T;
         const int b = min(tid * per, ncell + 1), e = min(b + per, ncell + 1);
         u32 sum = 0;
         for (int i = b; i < e; ++i) {
@@ -187,14 +189,14 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
         }
     }
     __syncthreads();
-    for (int c = tid; c <= ncell; c += 256) {
+    for (int c = tid; c <= ncell; c += T) {
         cell_start[c] = cnt[c];
         if (c < ncell) {
             cur[c] = cnt[c];
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += T) {
         int cx, cy;
         if (cell_of(g, kps[i].x, kps[i].y, cx, cy)) {
             const u32 pos = atomicAdd(&cur[cx * g.num_rows + cy], 1u);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
     }
     __syncthreads();
     // insertion order inside a cell is ascending keypoint index (common.cc:111-116)
-    for (int c = tid; c < ncell; c += 256) {
+    for (int c = tid; c < ncell; c += T) {
         const u32 b = cnt[c], e = cnt[c + 1];
         for (u32 i = b + 1; i < e; ++i) {
             const u32 v = items[i];
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const ovs_keypoint* __restri
     }
     __syncthreads();
     const int total = (int)cnt[ncell];
-    for (int j = tid; j < total; j += 256) {
+    for (int j = tid; j < total; j += T) {
         const u32 i = items[j];
         const ovs_keypoint kp = kps[i];
         entry[j] = make_uint4(__float_as_uint(kp.x), __float_as_uint(kp.y), (u32)kp.octave, i);
@@ -665,12 +667,15 @@ __device__ void window_topk(const frame_dev& f, const query_ctx& c, const u32* q
     }
 }
 
-template <int MODE>
+// GROUP lanes share a query: kGroup for batches (the device is full of queries), kGroupLive for a call with
+// a few problems that is waited for (a frame's 2000 queries fill 70 workgroups with eight lanes each; with
+// more lanes per query the scan of a window is shorter and more compute units take part).
+template <int MODE, int GROUP = kGroup>
 __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __restrict__ problems, proj_params pp) {
     const proj_problem& P = problems[blockIdx.y];
-    constexpr int QPB = 256 / kGroup;
-    const int qi = blockIdx.x * QPB + (threadIdx.x / kGroup);
-    const int gl = threadIdx.x & (kGroup - 1);
+    constexpr int QPB = 256 / GROUP;
+    const int qi = blockIdx.x * QPB + (threadIdx.x / GROUP);
+    const int gl = threadIdx.x & (GROUP - 1);
     if (qi >= P.q.n) {
         return;
     }
@@ -685,15 +690,15 @@ __global__ __launch_bounds__(256) void k_proj_candidates(const proj_problem* __r
         if (make_query_ctx<MODE>(pp, P.frm, P.q, qi, c)) {
             u32 qd[8];
             load_desc(P.q.desc + 32 * (size_t)qi, qd);
-            window_topk<kGroup, kTopK, MODE>(P.frm, c, qd, P.occupied, nullptr, top, total);
+            window_topk<GROUP, kTopK, MODE>(P.frm, c, qd, P.occupied, nullptr, top, total);
         }
         else if (gl == 0) {
             *P.err = OVS_ERR_OUT_OF_RANGE;
         }
     }
 #pragma unroll
-    for (int part = 0; part < (kTopK + kGroup - 1) / kGroup; ++part) {
-        const int slot = part * kGroup + gl;
+    for (int part = 0; part < (kTopK + GROUP - 1) / GROUP; ++part) {
+        const int slot = part * GROUP + gl;
         if (slot < kTopK) {
             u32 v = top[0];
 #pragma unroll
@@ -1746,16 +1751,39 @@ int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, int ma
     return launch_resolve_t<kModePlain>(d_prob, n_problems, max_n, pp, st);
 }
 
-void launch_candidates(dim3 grid, const proj_problem* d_prob, const proj_params& pp, hipStream_t st) {
+// candidate lists of n_problems problems with at most max_nq queries each
+void launch_candidates(int max_nq, int n_problems, const proj_problem* d_prob, const proj_params& pp, hipStream_t st) {
+    static const bool live_off = [] {
+        const char* e = std::getenv("OVS_GROUP_LIVE");
+        return e && std::string(e) == "8";
+    }();
+    const bool live = !live_off && n_problems <= kWideMaxProblems;
+    const int qpb = 256 / (live ? kGroupLive : kGroup);
+    const dim3 grid((max_nq + qpb - 1) / qpb, n_problems);
     if (kind_is_fuse(pp.kind)) {
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeFuse>, grid, dim3(256), 0, st, d_prob, pp);
+        if (live) {
+            OVS_LAUNCH("k_proj_candidates", (k_proj_candidates<kModeFuse, kGroupLive>), grid, dim3(256), 0, st, d_prob, pp);
+        }
+        else {
+            OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeFuse>, grid, dim3(256), 0, st, d_prob, pp);
+        }
     }
     else if (pp.kind == kTri) {
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeTri>, grid, dim3(256), 0, st, d_prob, pp);
+        if (live) {
+            OVS_LAUNCH("k_proj_candidates", (k_proj_candidates<kModeTri, kGroupLive>), grid, dim3(256), 0, st, d_prob, pp);
+        }
+        else {
+            OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModeTri>, grid, dim3(256), 0, st, d_prob, pp);
+        }
     }
     else {
         // kArea included: the take-over rule only acts in the resolve kernel
-        OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModePlain>, grid, dim3(256), 0, st, d_prob, pp);
+        if (live) {
+            OVS_LAUNCH("k_proj_candidates", (k_proj_candidates<kModePlain, kGroupLive>), grid, dim3(256), 0, st, d_prob, pp);
+        }
+        else {
+            OVS_LAUNCH("k_proj_candidates", k_proj_candidates<kModePlain>, grid, dim3(256), 0, st, d_prob, pp);
+        }
     }
 }
 
@@ -1774,7 +1802,9 @@ int launch_grid_build_kernel(int frames, const ovs_keypoint* d_kps, const uint8_
     if (bytes > kGridMaxLds) {
         return ovs::fail(OVS_ERR_UNSUPPORTED, "grid build: LDS plan exceeds the limit");
     }
-    auto kernel = in_lds ? k_grid_build<true> : k_grid_build<false>;
+    // a few frames that are waited for: four times the threads per frame
+    const bool wide = frames <= 8;
+    auto kernel = in_lds ? (wide ? k_grid_build<true, 1024> : k_grid_build<true, 256>) : (wide ? k_grid_build<false, 1024> : k_grid_build<false, 256>);
     if (bytes > 48 * 1024) {
         static std::mutex mu;
         static std::set<std::pair<int, const void*>> granted;
@@ -1787,7 +1817,7 @@ int launch_grid_build_kernel(int frames, const ovs_keypoint* d_kps, const uint8_
             granted.insert({dev, fn});
         }
     }
-    OVS_LAUNCH("k_grid_build", kernel, dim3(frames), dim3(256), bytes, st, d_kps, d_desc, d_counts, fixed_n, cap, g, d_cell_start, d_items, d_entry, d_gdesc);
+    OVS_LAUNCH("k_grid_build", kernel, dim3(frames), dim3(wide ? 1024 : 256), bytes, st, d_kps, d_desc, d_counts, fixed_n, cap, g, d_cell_start, d_items, d_entry, d_gdesc);
     return OVS_OK;
 }
 
@@ -1971,8 +2001,7 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
         }
     }
     if (nq) {
-        constexpr int QPB = 256 / kGroup;
-        launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
+        launch_candidates(static_cast<int>(nq), 1, d_prob, pp, st);
     }
     if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st)) != OVS_OK) {
         return rc;
@@ -2186,8 +2215,7 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
             OVS_LAUNCH("k_entries_from_list", k_entries_from_list, dim3((ne + 255) / 256), dim3(256), 0, st, d_eidx, static_cast<int>(ne), d_desc, d_entry, d_gdesc);
         }
         if (nq) {
-            constexpr int QPB = 256 / kGroup;
-            launch_candidates(dim3((nq + QPB - 1) / QPB, 1), d_prob, pp, st);
+            launch_candidates(static_cast<int>(nq), 1, d_prob, pp, st);
         }
         if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st)) != OVS_OK) {
             return rc;
@@ -2897,8 +2925,7 @@ int ovs_match_batch_current_and_last_dev(const ovs_keypoint* d_kps, const uint8_
         return rc;
     }
     if (n_frames > 1) {
-        constexpr int QPB = 256 / kGroup;
-        launch_candidates(dim3((cap + QPB - 1) / QPB, n_frames - 1), d_prob, pp, st);
+        launch_candidates(cap, n_frames - 1, d_prob, pp, st);
         if ((rc = launch_resolve(d_prob, n_frames - 1, cap, cap, pp, st)) != OVS_OK) {
             return rc;
         }
