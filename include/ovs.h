@@ -93,6 +93,20 @@ typedef struct ovs_orb ovs_orb;
 int ovs_orb_create(const ovs_orb_params* params, int device, ovs_orb** out);
 void ovs_orb_destroy(ovs_orb* h);
 
+/* The coefficients of cv::GaussianBlur(7 x 7, sigma 2) on 8-bit images (orb_extractor.cc:133) depend on the
+ * OpenCV the reference is built against (CMakeLists.txt:82-92 accepts 3.3.1 or newer; its Dockerfile builds
+ * 4.1.0).  Both forms are the exact integer sum  (sum_j sum_i k[j] k[i] p[y+j][x+i] + 2^15) >> 16, saturated:
+ *   OVS_BLUR_ROUNDED     k = round(256 g) = {18, 34, 49, 55, 49, 34, 18} (sum 257): OpenCV 3.3.1 (integer
+ *                        separable filter) up to 4.1.x (Q8.8 fixed point with the same rounded coefficients,
+ *                        which computes the same integers).  The default.
+ *   OVS_BLUR_NORMALISED  k = {18, 34, 48, 56, 48, 34, 18} (sum 256, rounding error diffused into the next
+ *                        coefficient, the centre takes the rest): OpenCV 3.4.9 / 4.2.0 and newer.
+ * Which release changed what is restated from the OpenCV sources from memory (they are not available to this
+ * build): a caller pins the choice by blurring one image with its own OpenCV. */
+enum { OVS_BLUR_ROUNDED = 0, OVS_BLUR_NORMALISED = 1 };
+int ovs_orb_set_blur_kernel(ovs_orb* h, int kernel_variant);
+int ovs_orb_get_blur_kernel(const ovs_orb* h);
+
 /* Getters / setters of orb_extractor.cc:146-203.  As in the reference, changing keypoints /
  * scale factor / levels re-runs initialize(); changing thresholds does not. */
 uint32_t ovs_orb_get_max_num_keypoints(const ovs_orb* h);

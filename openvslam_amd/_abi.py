@@ -11,6 +11,7 @@ OVS_ERR_UNSUPPORTED = -4
 OVS_ERR_OUT_OF_RANGE = -5
 
 DIR_NONE, DIR_FORWARD, DIR_BACKWARD = 0, 1, 2
+BLUR_ROUNDED, BLUR_NORMALISED = 0, 1
 
 # binary layout of cv::KeyPoint (28 bytes)
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),

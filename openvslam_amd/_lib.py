@@ -68,6 +68,8 @@ def _declare(L):
         getattr(L, "ovs_calc_" + name).argtypes = [C.c_uint32, C.c_float, A.f32p]
         getattr(L, "ovs_calc_" + name).restype = None
         getattr(L, "ovs_orb_get_" + name).argtypes = [vp, A.f32p]
+    L.ovs_orb_set_blur_kernel.argtypes = [vp, i]
+    L.ovs_orb_get_blur_kernel.argtypes = [vp]
     L.ovs_orb_create.argtypes = [C.POINTER(A.OrbParams), i, C.POINTER(vp)]
     L.ovs_orb_destroy.argtypes = [vp]
     L.ovs_orb_destroy.restype = None

@@ -189,6 +189,11 @@ public:
     orb_extractor& operator=(const orb_extractor&) = delete;
     virtual ~orb_extractor() { ovs_orb_destroy(h_); }
 
+    // which cv::GaussianBlur the surrounding build links (OVS_BLUR_ROUNDED: OpenCV up to 4.1.x, the default;
+    // OVS_BLUR_NORMALISED: 3.4.9 / 4.2.0 and newer); not part of the reference's class
+    void set_blur_kernel(int kernel_variant) { check(ovs_orb_set_blur_kernel(h_, kernel_variant)); }
+    int get_blur_kernel() const { return ovs_orb_get_blur_kernel(h_); }
+
     // extract(in_image, in_image_mask, keypts, out_descriptors), orb_extractor.cc:68-144
     template <class Mat, class KeyPoint>
     void extract(const Mat& in_image, const Mat& in_image_mask, std::vector<KeyPoint>& keypts, Mat& out_descriptors) {

@@ -940,7 +940,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(plan_dev p, image_src s, con
 // -------------------------------------------------------------------------------------------------
 // 7x7 Gaussian blur, sigma 2, BORDER_REFLECT_101, 8-bit: separable integer kernel
 // k = cvRound(g * 256) = {18, 34, 49, 55, 49, 34, 18}; exact integer row pass, column pass
-// (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path).
+// (sum + 2^15) >> 16 saturated (OpenCV 3.3.1 generic path; the Q8.8 fixed-point path of 3.4.1 .. 4.1.x computes
+// the same integers from the same coefficients).  A second instance uses the coefficients that sum to 256
+// exactly, {18, 34, 48, 56, 48, 34, 18} (OpenCV 3.4.9 / 4.2.0 and newer), selected per handle
+// (ovs_orb_set_blur_kernel).
 // -------------------------------------------------------------------------------------------------
 #ifndef OVS_BLUR_ROWS
 #define OVS_BLUR_ROWS 64
@@ -1015,8 +1018,14 @@ __device__ __forceinline__ void blur_ext_dword(int c, int w, u32& off, u32& sel)
 // j (0..3) is bytes j + 1 .. j + 7 of the twelve: instead of cutting it out with v_alignbyte, the taps
 // are laid over the three dwords as they are (weights of bytes outside the window are 0), which takes
 // 2 + 3 + 3 + 2 v_dot4 for the four columns and no shifts.
+// KSET: the coefficient set, OVS_BLUR_ROUNDED {18, 34, 49, 55, ...} or OVS_BLUR_NORMALISED {18, 34, 48, 56, ...}
+template <int KSET>
+struct blur_taps {
+    static constexpr u32 k0 = 18, k1 = 34, k2 = KSET == OVS_BLUR_NORMALISED ? 48 : 49, k3 = KSET == OVS_BLUR_NORMALISED ? 56 : 55;
+};
+template <int KSET>
 __device__ __forceinline__ blur_row blur_row_pass(u32 l, u32 c, u32 r) {
-    constexpr u32 k0 = 18, k1 = 34, k2 = 49, k3 = 55;
+    constexpr u32 k0 = blur_taps<KSET>::k0, k1 = blur_taps<KSET>::k1, k2 = blur_taps<KSET>::k2, k3 = blur_taps<KSET>::k3;
     constexpr u32 kL0 = (k0 << 8) | (k1 << 16) | (k2 << 24), kC0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
     constexpr u32 kL1 = (k0 << 16) | (k1 << 24), kC1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), kR1 = k0;
     constexpr u32 kL2 = (k0 << 24), kC2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), kR2 = k1 | (k0 << 8);
@@ -1031,12 +1040,13 @@ __device__ __forceinline__ blur_row blur_row_pass(u32 l, u32 c, u32 r) {
 
 // Column pass for one output row from four row pairs q[m][col] = h(row 2m) | h(row 2m + 1) << 16.
 // ODD = false: rows 0..6 of the eight;  ODD = true: rows 1..7.
-template <bool ODD>
+template <bool ODD, int KSET>
 __device__ __forceinline__ u32 blur_col_pass(const u32 (&q0)[4], const u32 (&q1)[4], const u32 (&q2)[4], const u32 (&q3)[4]) {
-    constexpr u32 w0 = ODD ? (18u << 16) : (18u | (34u << 16));
-    constexpr u32 w1 = ODD ? (34u | (49u << 16)) : (49u | (55u << 16));
-    constexpr u32 w2 = ODD ? (55u | (49u << 16)) : (49u | (34u << 16));
-    constexpr u32 w3 = ODD ? (34u | (18u << 16)) : 18u;
+    constexpr u32 k0 = blur_taps<KSET>::k0, k1 = blur_taps<KSET>::k1, k2 = blur_taps<KSET>::k2, k3 = blur_taps<KSET>::k3;
+    constexpr u32 w0 = ODD ? (k0 << 16) : (k0 | (k1 << 16));
+    constexpr u32 w1 = ODD ? (k1 | (k2 << 16)) : (k2 | (k3 << 16));
+    constexpr u32 w2 = ODD ? (k3 | (k2 << 16)) : (k2 | (k1 << 16));
+    constexpr u32 w3 = ODD ? (k1 | (k0 << 16)) : k0;
     u32 v[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1058,8 +1068,9 @@ struct blur_raw {
 
 // Per-lane, per-tile constants of the row fetch; BORDER: the tile touches the first or the last column
 // of the image, its lanes reorder what they load.
-template <bool BORDER>
+template <bool BORDER, int KSET>
 struct blur_src {
+    static constexpr int kset = KSET;
     const uint8_t* img;
     u32 pitch;
     u32 off_l, off_c, off_r;
@@ -1078,9 +1089,9 @@ struct blur_src {
     }
     __device__ __forceinline__ blur_row finish(const blur_raw& w) const {
         if (BORDER) {
-            return blur_row_pass(__builtin_amdgcn_perm(w.l, w.l, sel_l), __builtin_amdgcn_perm(w.c, w.c, sel_c), __builtin_amdgcn_perm(w.r, w.r, sel_r));
+            return blur_row_pass<KSET>(__builtin_amdgcn_perm(w.l, w.l, sel_l), __builtin_amdgcn_perm(w.c, w.c, sel_c), __builtin_amdgcn_perm(w.r, w.r, sel_r));
         }
-        return blur_row_pass(w.l, w.c, w.r);
+        return blur_row_pass<KSET>(w.l, w.c, w.r);
     }
 };
 
@@ -1117,8 +1128,8 @@ __device__ __forceinline__ void blur_tile_rows(const level_geom& g, const Src& s
             const int oo = o + 2 * i; // output rows oo, oo + 1: pairs i .. i + 3 (mod 4: the loop advances by four pairs)
             if (oo < nrows) {
                 step((o >> 1) + i + 3, (i + 3) & 3);
-                const u32 r0 = blur_col_pass<false>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
-                const u32 r1 = blur_col_pass<true>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
+                const u32 r0 = blur_col_pass<false, Src::kset>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
+                const u32 r1 = blur_col_pass<true, Src::kset>(q[i & 3], q[(i + 1) & 3], q[(i + 2) & 3], q[(i + 3) & 3]);
                 if (store_lane) {
                     u32 oc = (u32)col;
                     asm volatile("" : "+v"(oc)); // scalar row base + 32-bit lane offset, as for the loads
@@ -1136,16 +1147,17 @@ __device__ __forceinline__ void blur_tile_rows(const level_geom& g, const Src& s
     }
 }
 
+template <int KSET>
 __device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* img, u32 pitch, uint8_t* dst, int y0, int cb, int lane) {
     const int col = cb + 4 * lane;
     const bool store_lane = col < g.pitch;
     if (cb > 0 && cb + kBlurCols + 4 <= g.w) {
         // every source dword of the tile lies inside its image row
-        const blur_src<false> src{img, pitch, (u32)col - 4u, (u32)col, (u32)col + 4u, 0u, 0u, 0u};
+        const blur_src<false, KSET> src{img, pitch, (u32)col - 4u, (u32)col, (u32)col + 4u, 0u, 0u, 0u};
         blur_tile_rows(g, src, dst, y0, col, store_lane);
     }
     else {
-        blur_src<true> src;
+        blur_src<true, KSET> src;
         src.img = img;
         src.pitch = pitch;
         blur_ext_dword(col - 4, g.w, src.off_l, src.sel_l);
@@ -1155,6 +1167,7 @@ __device__ __forceinline__ void blur_tile(const level_geom& g, const uint8_t* im
     }
 }
 
+template <int KSET>
 __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t* __restrict__ blur, int n_frames) {
     const int groups = (p.total_blur_tiles + 3) >> 2; // four wave tiles per workgroup
     const int blk = xcd_contiguous_block(groups * n_frames);
@@ -1183,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_gauss7(plan_dev p, image_src s, uint8_t
     uint8_t* dst = blur + frame * p.frame_blur_bytes + g.blur_off + (long long)y0 * g.pitch;
     // (library planes are 256-byte aligned with a pitch that is a multiple of 64; a caller's level-0 image
     // may start anywhere and have any stride: the row fetch takes any alignment)
-    blur_tile(g, img, (u32)pitch64, dst, y0, cb, lane);
+    blur_tile<KSET>(g, img, (u32)pitch64, dst, y0, cb, lane);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2153,6 +2166,7 @@ struct ovs_orb {
     ovs::dev_buffer rect_mask;
     int rect_mask_w = 0, rect_mask_h = 0;
 
+    int blur_kernel = OVS_BLUR_ROUNDED; // coefficient set of the 7 x 7 blur
     // batch-capacity dependent buffers
     int batch_cap = 0;
     ovs::dev_buffer pyr, blur, slots, cell_counts, cand, lvl_xy, lvl_resp, lvl_count, qt_ws;
@@ -2640,6 +2654,14 @@ int ovs_orb_set_initial_fast_threshold(ovs_orb* h, uint32_t v) {
     h->plan.ini_thr = static_cast<int>(v);
     return OVS_OK;
 }
+int ovs_orb_get_blur_kernel(const ovs_orb* h) { return h->blur_kernel; }
+int ovs_orb_set_blur_kernel(ovs_orb* h, int kernel_variant) {
+    if (!h || (kernel_variant != OVS_BLUR_ROUNDED && kernel_variant != OVS_BLUR_NORMALISED)) {
+        return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "unknown blur kernel variant");
+    }
+    h->blur_kernel = kernel_variant;
+    return OVS_OK;
+}
 uint32_t ovs_orb_get_minimum_fast_threshold(const ovs_orb* h) { return h->min_fast_thr; }
 int ovs_orb_set_minimum_fast_threshold(ovs_orb* h, uint32_t v) {
     h->min_fast_thr = v;
@@ -2778,8 +2800,14 @@ int ovs_orb_extract_batch_dev(ovs_orb* h, const uint8_t* d_imgs, int n_frames, i
         OVS_HIP(hipEventRecord(h->ev_fork, stream));
         OVS_HIP(hipStreamWaitEvent(blur_stream, h->ev_fork, 0));
     }
-    OVS_LAUNCH("k_gauss7", k_gauss7, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, blur_stream,
-               p, src, h->blur.as<uint8_t>(), n_frames);
+    if (h->blur_kernel == OVS_BLUR_NORMALISED) {
+        OVS_LAUNCH("k_gauss7", k_gauss7<OVS_BLUR_NORMALISED>, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, blur_stream,
+                   p, src, h->blur.as<uint8_t>(), n_frames);
+    }
+    else {
+        OVS_LAUNCH("k_gauss7", k_gauss7<OVS_BLUR_ROUNDED>, dim3(xcd_grid((p.total_blur_tiles + 3) / 4 * n_frames)), dim3(256), 0, blur_stream,
+                   p, src, h->blur.as<uint8_t>(), n_frames);
+    }
     if (forked) {
         OVS_HIP(hipEventRecord(h->ev_join, blur_stream));
     }

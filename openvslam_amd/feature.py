@@ -127,6 +127,13 @@ class orb_extractor:
         check(lib().ovs_orb_download_blurred_level(self._h, frame, level, A.ptr(out, A.u8p), w))
         return out
 
+    # ---- coefficients of the 7 x 7 blur: which cv::GaussianBlur the caller's OpenCV has (see include/ovs.h)
+    def set_blur_kernel(self, variant):
+        check(lib().ovs_orb_set_blur_kernel(self._h, variant))
+
+    def get_blur_kernel(self):
+        return lib().ovs_orb_get_blur_kernel(self._h)
+
     # ---- getters / setters (orb_extractor.cc:146-203) -------------------------------------------
     def get_max_num_keypoints(self):
         return lib().ovs_orb_get_max_num_keypoints(self._h)

@@ -56,6 +56,8 @@ int ovo_fast_9_16(const uint8_t* img, int w, int h, size_t stride, int threshold
                   ovs_keypoint* kps, int cap);
 /* cv::GaussianBlur(img, img, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1 */
 int ovo_gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+int ovo_gaussian_blur_7x7_variant(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride, int kernel_variant);
+void ovo_gaussian_kernel_7_q8_normalised(int32_t out[7]);
 /* the integer kernel cvRound(getGaussianKernel(7, 2) * 256) */
 void ovo_gaussian_kernel_7_q8(int32_t out[7]);
 
@@ -78,6 +80,7 @@ int ovo_orb_set_scale_factor(ovo_orb* h, float v);
 int ovo_orb_set_num_scale_levels(ovo_orb* h, uint32_t v);
 int ovo_orb_set_initial_fast_threshold(ovo_orb* h, uint32_t v);
 int ovo_orb_set_minimum_fast_threshold(ovo_orb* h, uint32_t v);
+int ovo_orb_set_blur_kernel(ovo_orb* h, int kernel_variant);
 int ovo_orb_get_num_keypts_per_level(const ovo_orb* h, uint32_t* out);
 int ovo_orb_get_u_max(const ovo_orb* h, int32_t* out16);
 int ovo_orb_extract(ovo_orb* h, const uint8_t* img, int width, int height, size_t stride,

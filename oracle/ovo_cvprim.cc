@@ -372,6 +372,36 @@ void gaussian_kernel_7_q8(int32_t out[7]) {
     }
 }
 
+// The coefficients of the 8-bit GaussianBlur from OpenCV 3.4.9 / 4.2.0 on (imgproc: "bit-exact" GaussianBlur,
+// getGaussianKernelFixedPoint_ED): the normalised kernel in Q8.8 with the rounding error of every coefficient
+// carried into the next (error diffusion over the first half, mirrored) and the centre taking what is left
+// of 256, so that the coefficients sum to 256 exactly.  OpenCV evaluates this in its software doubles
+// (softdouble exp); plain IEEE doubles give the same Q8.8 values here (no product lies near a rounding
+// boundary: 17.96, 33.52, 48.34).  Restated from the published algorithm: PARITY UNPINNED.
+void gaussian_kernel_7_q8_normalised(int32_t out[7]) {
+    const int n = 7;
+    const double sigmaX = 2.0;
+    const double scale2X = -0.5 / (sigmaX * sigmaX);
+    double values[7], sum = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        values[i] = std::exp(scale2X * x * x);
+        sum += values[i];
+    }
+    sum = 1.0 / sum;
+    double err = 0.0;
+    int32_t acc = 0;
+    for (int i = 0; i < n / 2; i++) {
+        const double adj_v = values[i] * sum * 256.0 + err;
+        const int32_t v0 = cv_round(adj_v);
+        err = adj_v - static_cast<double>(v0);
+        out[i] = v0;
+        out[n - 1 - i] = v0;
+        acc += v0;
+    }
+    out[n / 2] = 256 - 2 * acc;
+}
+
 static inline int reflect101(int p, int len) {
     // cv::borderInterpolate(p, len, BORDER_REFLECT_101)
     if (static_cast<unsigned>(p) < static_cast<unsigned>(len)) {
@@ -391,9 +421,14 @@ static inline int reflect101(int p, int len) {
     return p;
 }
 
-void gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride) {
+void gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride, int kernel_variant) {
     int32_t k[7];
-    gaussian_kernel_7_q8(k);
+    if (kernel_variant == OVS_BLUR_NORMALISED) {
+        gaussian_kernel_7_q8_normalised(k);
+    }
+    else {
+        gaussian_kernel_7_q8(k);
+    }
     std::vector<int32_t> rows(static_cast<size_t>(w) * h);
     for (int y = 0; y < h; ++y) {
         const uint8_t* S = src + static_cast<size_t>(y) * sstride;
@@ -457,10 +492,19 @@ int ovo_gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint
     if (!src || !dst || w <= 0 || h <= 0) {
         return ovo::fail(OVS_ERR_INVALID_ARGUMENT, "blur: empty image");
     }
-    ovo::gaussian_blur_7x7(src, w, h, sstride, dst, dstride);
+    ovo::gaussian_blur_7x7(src, w, h, sstride, dst, dstride, OVS_BLUR_ROUNDED);
+    return OVS_OK;
+}
+
+int ovo_gaussian_blur_7x7_variant(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride, int kernel_variant) {
+    if (!src || !dst || w <= 0 || h <= 0 || (kernel_variant != OVS_BLUR_ROUNDED && kernel_variant != OVS_BLUR_NORMALISED)) {
+        return ovo::fail(OVS_ERR_INVALID_ARGUMENT, "blur: empty image or unknown kernel variant");
+    }
+    ovo::gaussian_blur_7x7(src, w, h, sstride, dst, dstride, kernel_variant);
     return OVS_OK;
 }
 
 void ovo_gaussian_kernel_7_q8(int32_t out[7]) { ovo::gaussian_kernel_7_q8(out); }
+void ovo_gaussian_kernel_7_q8_normalised(int32_t out[7]) { ovo::gaussian_kernel_7_q8_normalised(out); }
 
 } // extern "C"

@@ -37,7 +37,7 @@ inline int cv_ceil(double v) {
 float fast_atan2(float y, float x);
 void resize_linear_u8(const uint8_t* src, int sw, int sh, size_t sstride, uint8_t* dst, int dw, int dh, size_t dstride);
 void fast_9_16(const uint8_t* img, int cols, int rows, size_t step, int threshold, std::vector<ovs_keypoint>& keypoints);
-void gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride);
+void gaussian_blur_7x7(const uint8_t* src, int w, int h, size_t sstride, uint8_t* dst, size_t dstride, int kernel_variant);
 void gaussian_kernel_7_q8(int32_t out[7]);
 
 // util/trigonometric.h

@@ -181,6 +181,7 @@ struct ovo_orb {
     unsigned int ini_fast_thr_ = 20;
     unsigned int min_fast_thr = 7;
     std::vector<std::vector<float>> mask_rects_;
+    int blur_kernel = OVS_BLUR_ROUNDED; // coefficients of cv::GaussianBlur (orb_extractor.cc:133), see ovs.h
 
     static constexpr unsigned int fast_patch_size_ = 31;
     static constexpr int fast_half_patch_size_ = fast_patch_size_ / 2;
@@ -681,7 +682,7 @@ int ovo_orb::extract(const ovo::image& image, const ovo::image& image_mask, std:
             stage_timer t(stage_seconds_[4]);
             const auto& src = image_pyramid_.at(level);
             blurred_image.create(src.rows, src.cols);
-            ovo::gaussian_blur_7x7(src.data.data(), src.cols, src.rows, src.step, blurred_image.data.data(), blurred_image.step);
+            ovo::gaussian_blur_7x7(src.data.data(), src.cols, src.rows, src.step, blurred_image.data.data(), blurred_image.step, blur_kernel);
         }
         {
             stage_timer t(stage_seconds_[5]);
@@ -793,6 +794,13 @@ int ovo_orb_set_num_scale_levels(ovo_orb* h, uint32_t v) {
 }
 int ovo_orb_set_initial_fast_threshold(ovo_orb* h, uint32_t v) {
     h->ini_fast_thr_ = v;
+    return OVS_OK;
+}
+int ovo_orb_set_blur_kernel(ovo_orb* h, int kernel_variant) {
+    if (kernel_variant != OVS_BLUR_ROUNDED && kernel_variant != OVS_BLUR_NORMALISED) {
+        return ovo::fail(OVS_ERR_INVALID_ARGUMENT, "unknown blur kernel variant");
+    }
+    h->blur_kernel = kernel_variant;
     return OVS_OK;
 }
 int ovo_orb_set_minimum_fast_threshold(ovo_orb* h, uint32_t v) {

@@ -53,6 +53,9 @@ def _declare(L):
     L.ovo_fast_9_16.argtypes = [A.u8p, i, i, sz, i, A.kpp, i]
     L.ovo_gaussian_blur_7x7.argtypes = [A.u8p, i, i, sz, A.u8p, sz]
     L.ovo_gaussian_kernel_7_q8.argtypes = [A.i32p]
+    L.ovo_gaussian_kernel_7_q8_normalised.argtypes = [A.i32p]
+    L.ovo_gaussian_blur_7x7_variant.argtypes = [A.u8p, i, i, sz, A.u8p, sz, i]
+    L.ovo_orb_set_blur_kernel.argtypes = [C.c_void_p, i]
     for name in ("scale_factors", "inv_scale_factors", "level_sigma_sq", "inv_level_sigma_sq"):
         getattr(L, "ovo_calc_" + name).argtypes = [C.c_uint32, C.c_float, A.f32p]
         getattr(L, "ovo_calc_" + name).restype = None
@@ -148,6 +151,9 @@ class OrbExtractor:
         if getattr(self, "_h", None):
             lib().ovo_orb_destroy(self._h)
             self._h = None
+
+    def set_blur_kernel(self, variant):
+        check(lib().ovo_orb_set_blur_kernel(self._h, variant))
 
     def extract(self, img, mask=None, cap=None):
         img = np.ascontiguousarray(img, dtype=np.uint8)

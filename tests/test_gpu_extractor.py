@@ -50,23 +50,53 @@ def test_extract_low_texture_uses_min_threshold():
     _compare(img, max_num_keypts=1000)
 
 
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("w", [253, 254, 255, 256, 257, 259, 260, 261, 262, 263, 511, 514, 517, 520, 771])
-def test_blur_borders_every_width_class(w):
+def test_blur_borders_every_width_class(w, variant):
     # the blur's tiles are 256 columns wide: widths around the tile boundaries put the right image
     # border at every byte position of a lane's dwords (reflected columns inside the lane's own dword,
     # in its right neighbour, in the first dword of the next tile), with one, two and three column tiles;
     # level widths w / 1.2^k add further residues, and odd widths put the rows of the uploaded image at
-    # odd addresses.  Noise: every pixel differs from its neighbours.
+    # odd addresses.  Noise: every pixel differs from its neighbours.  Both coefficient sets of
+    # cv::GaussianBlur (ovs_orb_set_blur_kernel: rounded, sum 257; normalised, sum 256).
     rng = np.random.default_rng(w)
     img = rng.integers(0, 256, (97, w), dtype=np.uint8)
     ref = oracle.OrbExtractor(max_num_keypts=300, num_levels=3)
+    ref.set_blur_kernel(variant)
     ref.extract(img, None)
     ext = orb_extractor(orb_params(max_num_keypts=300, num_levels=3))
+    ext.set_blur_kernel(variant)
+    assert ext.get_blur_kernel() == variant
     ext.extract(img, None)
     for lvl in range(3):
         rb = ref.blurred_level(lvl)
         assert rb is not None
         assert np.array_equal(ext.blurred_level(lvl), rb), "blurred level %d differs at width %d" % (lvl, w)
+
+
+def test_blur_kernel_variants_end_to_end():
+    """The normalised coefficient set (OpenCV >= 3.4.9 / 4.2.0) through the whole extraction: keypoints are
+    the same as with the rounded set (the blur only feeds the descriptors), descriptors equal the oracle's for
+    that set and differ from the other set's in a few bits; bright saturated areas stay at 255 in both."""
+    img = synth.make_frame(752, 480, seed=77)
+    img[:40, :60] = 255
+    out = {}
+    for variant in (0, 1):
+        ref = oracle.OrbExtractor(max_num_keypts=1000)
+        ref.set_blur_kernel(variant)
+        rk, rd = ref.extract(img)
+        ext = orb_extractor(orb_params(max_num_keypts=1000))
+        ext.set_blur_kernel(variant)
+        gk, gd = ext.extract(img)
+        assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+        assert np.array_equal(ext.blurred_level(0), ref.blurred_level(0)) and ext.blurred_level(0)[:30, :50].min() == 255
+        out[variant] = (gk, gd)
+    assert out[0][0].tobytes() == out[1][0].tobytes()
+    differing = np.unpackbits(out[0][1] ^ out[1][1]).sum()
+    assert 0 < differing < 0.05 * out[0][1].size * 8
+    from openvslam_amd._lib import OvsError
+    with pytest.raises(OvsError):
+        orb_extractor(orb_params()).set_blur_kernel(7)
 
 
 @pytest.mark.parametrize("levels,n,w,h", [(1, 3000, 1241, 376), (2, 2500, 640, 480), (8, 8000, 1241, 376),

@@ -236,3 +236,36 @@ def test_gaussian_kernel():
     k = np.zeros(7, dtype=np.int32)
     L.ovo_gaussian_kernel_7_q8(A.ptr(k, A.i32p))
     assert k.tolist() == [18, 34, 49, 55, 49, 34, 18]
+
+
+def test_gaussian_kernel_normalised_variant():
+    """The coefficient set of OpenCV >= 3.4.9 / 4.2.0 (error diffusion, sum exactly 256) and what the two sets
+    do to an image: identical arithmetic, so a constant image stays constant under the normalised set while
+    the rounded set (sum 257, gain 257^2 / 2^16 = 1.0078) lifts bright constants by up to two grey levels; on
+    noise the two differ by at most two grey levels.  Parity unpinned: no OpenCV here to blur with."""
+    k = np.zeros(7, dtype=np.int32)
+    L.ovo_gaussian_kernel_7_q8_normalised(A.ptr(k, A.i32p))
+    assert k.tolist() == [18, 34, 48, 56, 48, 34, 18] and k.sum() == 256
+    # by hand: 17.9608 -> 18 (err -0.0392); 33.5552 - 0.0392 -> 34 (err -0.4840); 48.8225 - 0.4840 -> 48; centre 256 - 200
+    rng = np.random.default_rng(1)
+    for img in (np.full((40, 50), 200, np.uint8), np.full((40, 50), 77, np.uint8), rng.integers(0, 256, (64, 80), dtype=np.uint8)):
+        out = [np.zeros_like(img) for _ in range(2)]
+        for variant in (0, 1):
+            oracle.check(L.ovo_gaussian_blur_7x7_variant(A.ptr(img, A.u8p), img.shape[1], img.shape[0], img.shape[1], A.ptr(out[variant], A.u8p),
+                                                         img.shape[1], variant))
+        plain = np.zeros_like(img)
+        oracle.check(L.ovo_gaussian_blur_7x7(A.ptr(img, A.u8p), img.shape[1], img.shape[0], img.shape[1], A.ptr(plain, A.u8p), img.shape[1]))
+        assert np.array_equal(plain, out[0])
+        assert np.abs(out[0].astype(int) - out[1].astype(int)).max() <= 2
+        if img.min() == img.max():
+            v = int(img[0, 0])
+            assert (out[1] == v).all()
+            assert (out[0] == (v * 257 * 257 + 32768) >> 16).all()  # 200 -> 202, 77 -> 78
+    # brute force of the double sum on one pixel, reflected borders included
+    img = rng.integers(0, 256, (9, 9), dtype=np.uint8)
+    got = np.zeros_like(img)
+    oracle.check(L.ovo_gaussian_blur_7x7_variant(A.ptr(img, A.u8p), 9, 9, 9, A.ptr(got, A.u8p), 9, 1))
+    refl = lambda p, n: -p if p < 0 else (2 * n - 2 - p if p >= n else p)  # noqa: E731
+    for (y, x) in ((0, 0), (4, 4), (8, 1)):
+        s = sum(int(k[j]) * int(k[i]) * int(img[refl(y + j - 3, 9), refl(x + i - 3, 9)]) for j in range(7) for i in range(7))
+        assert got[y, x] == min((s + 32768) >> 16, 255)
