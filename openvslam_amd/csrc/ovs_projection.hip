@@ -71,6 +71,7 @@ struct frame_dev {
     const u32* cell_start; // num_cols * num_rows + 1
     const uint4* g_entry;  // grid order: {x bits, y bits, octave, keypoint index}
     const uint4* g_desc;   // grid order: two uint4 per keypoint
+    int n_entries_plus1;   // ranged problems: number of list entries + 1; 0: a grid, cell_start[cells] holds it
     const float* inv_level_sigma_sq; // kFuseReplace only
     // kTri only
     const double* bearings; // n x 3: bearings_ of the searched keyframe
@@ -1388,6 +1389,11 @@ __global__ __launch_bounds__(kWideThreads) void k_proj_resolve_wide(const proj_p
         if (cur[k] != kNoKey32) {
             const u32 e = sel_entry(cur[k]);
             acc[k] = (int)entry_idx[e];
+            if ((u32)acc[k] >= (u32)n) {
+                *P.err = OVS_ERR_OUT_OF_RANGE; // cannot happen with lists of this frame: never index past it
+                acc[k] = -1;
+                continue;
+            }
             atomicMax(&P.matched[acc[k]], q); // the last taker of a keypoint that nobody held
             ++mynum;
             if (orient) {
@@ -1421,6 +1427,321 @@ __global__ __launch_bounds__(kWideThreads) void k_proj_resolve_wide(const proj_p
                 }
                 else {
                     P.matched[acc[k]] = -2; // after every taker has posted (barriers above)
+                }
+                ++removed;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        if (q < nq) {
+            P.acc_idx[q] = acc[k];
+        }
+    }
+    const u32 kept = wave_sum_u32(mynum - removed);
+    if (lane == 0) {
+        red[wave] = kept;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 num = 0;
+        for (int w = 0; w < kWideThreads / 64; ++w) {
+            num += red[w];
+        }
+        *P.num_matches = num;
+    }
+}
+
+// ---- resolution by a whole workgroup, for the matchers with a ratio test --------------------------------
+// projection::match_frame_and_landmarks (projection.cc:11-82) and robust::brute_force_match / bow_tree::match_*
+// (robust.cc:250-285, bow_tree.cc:60-95) accept a query's best free candidate only if it also passes a test
+// against the second best free one, and a query that fails it holds nothing.  The outcome of the serial
+// walk is still the one assignment in which every query's decision is the reference's decision function
+// applied to the keypoints that queries with smaller indices hold; but a decision can flip both ways while
+// that set grows (same-octave rule of projection.cc:69-73), so the words "smallest index posted" are rebuilt
+// from the current decisions in every round instead of only decreasing: every query decides from the words
+// of the previous round, and a round that changes no decision is the serial result (the decision of query q
+// is final after q rounds at the latest; in practice after as many rounds as the longest chain of queries
+// that push each other on, about ten).  Lists are kept whole: a query whose list does not hold two free
+// candidates while its window holds more gets eight more behind it (up to kJacobiRowsMax rows, one wave per
+// query, all waiting queries at once when the others have settled).  Pool or rows exhausted: the kernel
+// reports kResolveOverflow and the host runs the single-wave kernel on the same lists.
+constexpr int kJacobiPool = 256;    // continuation rows in LDS
+constexpr int kJacobiRowsMax = 3;   // rows of eight candidates per query (the first included)
+constexpr int kResolveOverflow = 1000;
+__host__ __device__ inline size_t jacobi_lds_bytes(int n, int nq) { return (2 * (size_t)max(n, 1) + (size_t)max(nq, 1) * kTopK) * 4; }
+
+template <int KIND>
+__global__ __launch_bounds__(kWideThreads) void k_proj_resolve_jacobi(const proj_problem* __restrict__ problems, proj_params pp_arg, int lds_n) {
+    proj_params pp = pp_arg;
+    pp.kind = KIND;
+    extern __shared__ u32 wide_sm[];
+    __shared__ u32 hist[32];
+    __shared__ u32 order[32];
+    __shared__ ovs_sort::sort_frame sort_stack[ovs_sort::kSortStackEntries];
+    __shared__ u32 pool[kJacobiPool * kTopK];
+    __shared__ u32 queue[kJacobiPool];      // query | row slot << 20 of a waiting query
+    __shared__ u32 n_queue, n_pool, overflow;
+    __shared__ u32 moved_flag[3];
+    __shared__ u32 keep_mask;
+    __shared__ u32 red[kWideThreads / 64];
+    const proj_problem& P = problems[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.frm.n, nq = P.q.n;
+    const bool orient = pp.check_orientation && KIND == kRange;
+    u32* holder = wide_sm;              // lds_n words: smallest index of the blocking queries that hold the entry
+    u32* entry_info = wide_sm + lds_n;  // keypoint index | octave << 24
+    u32* rows = wide_sm + 2 * lds_n;    // nq x kTopK selection keys
+    const u32 athr = KIND == kFrameLms ? kThrHigh : kThrLow;
+    const int n_entries = P.frm.n_entries_plus1 ? P.frm.n_entries_plus1 - 1 : (int)P.frm.cell_start[P.frm.grid.num_cols * P.frm.grid.num_rows];
+    for (int i = tid; i < n; i += kWideThreads) {
+        P.matched[i] = -1;
+    }
+    for (int i = tid; i < min(n_entries, lds_n); i += kWideThreads) {
+        const uint4 en = P.frm.g_entry[i];
+        entry_info[i] = (en.w & 0xFFFFFFu) | (en.z << 24);
+    }
+    for (int i = tid; i < nq * kTopK; i += kWideThreads) {
+        const u64 key = P.lists[i];
+        rows[i] = key == kNoKey ? kNoKey32 : (u32)(key >> 20);
+    }
+    if (tid < 32) {
+        hist[tid] = 0;
+    }
+    if (tid < 3) {
+        moved_flag[tid] = 0;
+    }
+    if (tid == 0) {
+        n_queue = 0;
+        n_pool = 0;
+        overflow = 0;
+    }
+    u32 decision[kWideQueries], total[kWideQueries], last_listed[kWideQueries];
+    int ext[kWideQueries][kJacobiRowsMax - 1], nrows[kWideQueries];
+    bool blocks[kWideQueries], live[kWideQueries];
+    int waiting[kWideQueries]; // 0: no, 1: wants more candidates, 2: queued for them
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        decision[k] = kNoKey32;
+        total[k] = 0;
+        last_listed[k] = 0;
+        nrows[k] = 1;
+#pragma unroll
+        for (int r = 0; r < kJacobiRowsMax - 1; ++r) {
+            ext[k][r] = -1;
+        }
+        blocks[k] = false;
+        live[k] = false;
+        waiting[k] = 0;
+        if (q < nq && P.q.valid[q]) {
+            total[k] = P.totals[q];
+            live[k] = total[k] != 0;
+            blocks[k] = KIND == kRange ? true : (P.q.has_obs ? P.q.has_obs[q] != 0 : true);
+        }
+    }
+    auto row_ptr = [&](int k, int q, int r) -> const u32* { return r == 0 ? rows + (size_t)q * kTopK : pool + ext[k][r - 1] * kTopK; };
+    auto octave_of = [&](u32 key) { return (int)(entry_info[sel_entry(key)] >> 24); };
+    // the reference's decision for a query from its best and second best free candidates (kNoKey32: none)
+    auto accepts = [&](u32 best, u32 second) {
+        const u32 bd = sel_dist(best);
+        if (bd > athr) {
+            return false;
+        }
+        const u32 sd = second == kNoKey32 ? kMaxDist : sel_dist(second);
+        if (KIND == kFrameLms) {
+            // Lowe's ratio only between candidates of the same octave, projection.cc:69-73
+            const int bl = octave_of(best), slv = second == kNoKey32 ? -1 : octave_of(second);
+            return !(bl == slv && (float)bd > __fmul_rn(pp.lowe, (float)sd));
+        }
+        return !(__fmul_rn(pp.lowe, (float)sd) < (float)bd); // robust.cc:270-281, bow_tree.cc:80-87
+    };
+    __syncthreads();
+
+    for (int round = 0;; ++round) {
+        // the words of this round from the decisions of the last one
+        for (int i = tid; i < lds_n; i += kWideThreads) {
+            holder[i] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            if (decision[k] != kNoKey32 && blocks[k]) {
+                atomicMin(&holder[sel_entry(decision[k])], (u32)(tid + k * kWideThreads));
+            }
+        }
+        __syncthreads();
+        int moved = 0;
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            const u32 q = (u32)(tid + k * kWideThreads);
+            if (!live[k] || waiting[k] != 0) {
+                continue;
+            }
+            u32 best = kNoKey32, second = kNoKey32, last = kNoKey32;
+            int found = 0;
+            for (int r = 0; r < nrows[k]; ++r) {
+                const u32* row = row_ptr(k, (int)q, r);
+#pragma unroll
+                for (int c = 0; c < kTopK; ++c) {
+                    const u32 key = row[c];
+                    if (key != kNoKey32) {
+                        last = key;
+                        if (found < 2 && !(holder[sel_entry(key)] < q)) {
+                            if (found == 0) {
+                                best = key;
+                            }
+                            else {
+                                second = key;
+                            }
+                            ++found;
+                        }
+                    }
+                }
+            }
+            // candidates that are not listed lie behind `last`: they matter only while one of them could
+            // still be accepted or could still fail the ratio test (as in the single-wave kernel)
+            bool more = false;
+            if (found < 2 && total[k] > (u32)(nrows[k] * kTopK) && last != kNoKey32) {
+                const u32 last_d = sel_dist(last);
+                more = found == 0 ? last_d <= athr : (sel_dist(best) <= athr && (float)sel_dist(best) > __fmul_rn(pp.lowe, (float)last_d));
+            }
+            u32 d = kNoKey32;
+            if (more) {
+                waiting[k] = 1;
+                last_listed[k] = last;
+            }
+            else if (found > 0 && accepts(best, second)) {
+                d = best;
+            }
+            moved |= d != decision[k] ? 1 : 0;
+            decision[k] = d;
+        }
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            if (waiting[k] == 1) {
+                const u32 q = (u32)(tid + k * kWideThreads);
+                const u32 slot = atomicAdd(&n_pool, 1u);
+                if (nrows[k] >= kJacobiRowsMax || slot >= (u32)kJacobiPool) {
+                    overflow = 1u;
+                }
+                else {
+                    const u32 at = atomicAdd(&n_queue, 1u);
+                    queue[at] = q | (slot << 20);
+                    pool[slot * kTopK] = last_listed[k]; // for the wave that fills the row: where the list ends so far
+                    ext[k][nrows[k] - 1] = (int)slot;
+                    waiting[k] = 2;
+                }
+            }
+        }
+        if (moved) {
+            moved_flag[round % 3] = 1u;
+        }
+        if (tid == 0) {
+            moved_flag[(round + 1) % 3] = 0u; // last read two rounds ago
+        }
+        __syncthreads();
+        if (overflow) {
+            if (tid == 0) {
+                *P.err = kResolveOverflow;
+            }
+            return;
+        }
+        if (moved_flag[round % 3] != 0u) {
+            if (round >= kWideMaxRounds) {
+                if (tid == 0) {
+                    *P.err = kResolveOverflow; // cannot happen: query q is final after q rounds
+                }
+                return;
+            }
+            continue;
+        }
+        // everybody who is not waiting has settled
+        const int queued = (int)n_queue;
+        if (queued == 0) {
+            break;
+        }
+        for (int e = wave; e < queued; e += kWideThreads / 64) {
+            const int q = (int)(queue[e] & 0xFFFFFu), slot = (int)(queue[e] >> 20);
+            const u32 last = pool[slot * kTopK]; // the last candidate listed so far, left there by the query's thread
+            query_ctx c;
+            make_query_ctx<kModePlain>(pp, P.frm, P.q, q, c);
+            u32 qd[8];
+            load_desc(P.q.desc + 32 * (size_t)q, qd);
+            u32 sel[kTopK];
+            u32 t;
+            window_topk<64, kTopK, kModePlain>(P.frm, c, qd, P.occupied, nullptr, sel, t, last + 1u);
+            if (lane < kTopK) {
+                u32 v = sel[0];
+#pragma unroll
+                for (int k = 1; k < kTopK; ++k) {
+                    v = lane == k ? sel[k] : v;
+                }
+                pool[slot * kTopK + lane] = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            n_queue = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            if (waiting[k] == 2) {
+                waiting[k] = 0;
+                ++nrows[k];
+            }
+        }
+        __syncthreads();
+    }
+
+    // every query now holds its final decision
+    u32 mynum = 0;
+    int acc[kWideQueries], bin[kWideQueries];
+#pragma unroll
+    for (int k = 0; k < kWideQueries; ++k) {
+        const int q = tid + k * kWideThreads;
+        acc[k] = -1;
+        bin[k] = 0;
+        if (decision[k] != kNoKey32) {
+            acc[k] = (int)(entry_info[sel_entry(decision[k])] & 0xFFFFFFu);
+            if ((u32)acc[k] >= (u32)n) {
+                *P.err = OVS_ERR_OUT_OF_RANGE; // cannot happen with lists of this frame: never index past it
+                acc[k] = -1;
+                continue;
+            }
+            atomicMax(&P.matched[acc[k]], q); // the last taker of a keypoint that nobody held
+            ++mynum;
+            if (orient) {
+                const float qa = P.q.angle[q], ca = P.frm.kps[acc[k]].angle;
+                bin[k] = angle_bin(pp.angle_sign >= 0 ? __fsub_rn(qa, ca) : __fsub_rn(ca, qa));
+                if (bin[k] < 0 || 30 <= bin[k]) {
+                    *P.err = OVS_ERR_OUT_OF_RANGE; // angle_histogram_.at(bin) would throw
+                    bin[k] = 0;
+                }
+                atomicAdd(&hist[bin[k]], 1u);
+            }
+        }
+    }
+    u32 removed = 0;
+    if (orient) {
+        __syncthreads();
+        if (wave == 0) {
+            const u32 mask = kept_rotation_bins(hist, order, sort_stack);
+            if (lane == 0) {
+                keep_mask = mask;
+            }
+        }
+        __syncthreads();
+        const u32 keep = keep_mask;
+#pragma unroll
+        for (int k = 0; k < kWideQueries; ++k) {
+            if (0 <= acc[k] && !((keep >> bin[k]) & 1u)) {
+                if (pp.per_query_output) {
+                    acc[k] = -1;
+                }
+                else {
+                    P.matched[acc[k]] = -2;
                 }
                 ++removed;
             }
@@ -1547,6 +1868,7 @@ __global__ __launch_bounds__(256) void k_batch_setup(const ovs_keypoint* __restr
         P.frm.cell_start = cell_start + (size_t)f * (ncell + 1);
         P.frm.g_entry = g_entry + qo;
         P.frm.g_desc = g_desc + 2 * qo;
+        P.frm.n_entries_plus1 = 0;
         P.q.n = n_last;
         P.q.reproj_xy = reproj_xy + 2 * qo;
         P.q.x_right = nullptr;
@@ -1723,8 +2045,47 @@ int launch_resolve_wide(Kernel kernel, const proj_problem* d_prob, int n_problem
     return OVS_OK;
 }
 
-int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, int max_nq, const proj_params& pp, hipStream_t st) {
-    if (wide_resolve_applies(pp, n_problems, max_n, max_nq)) {
+// The ratio-test matchers on the workgroup-wide kernel that rebuilds its words every round.  Opt-in
+// (OVS_RESOLVE=wide): the kernel passed the projection / brute-force / BoW parity tests on the device, but its
+// last change (and the change of frame staging that goes with it) has not been run there since, so the
+// single-wave kernel stays the default for these matchers.
+bool jacobi_resolve_applies(const proj_params& pp, int n_problems, int max_n, int max_nq) {
+    static const bool opted_in = [] {
+        const char* e = std::getenv("OVS_RESOLVE");
+        return e && std::string(e) == "wide";
+    }();
+    (void)n_problems;
+    return opted_in && (pp.kind == kFrameLms || pp.kind == kRange) && max_nq <= kWideThreads * kWideQueries && jacobi_lds_bytes(max_n, max_nq) <= 140 * 1024;
+}
+
+template <typename Kernel>
+int launch_resolve_jacobi(Kernel kernel, const proj_problem* d_prob, int n_problems, int max_n, int max_nq, const proj_params& pp, hipStream_t st) {
+    const size_t bytes = jacobi_lds_bytes(max_n, max_nq);
+    if (bytes > 48 * 1024) {
+        static std::mutex mu;
+        static std::set<std::pair<int, const void*>> granted;
+        int dev = 0;
+        OVS_HIP(hipGetDevice(&dev));
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!granted.count({dev, fn})) {
+            OVS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
+            granted.insert({dev, fn});
+        }
+    }
+    OVS_LAUNCH("k_proj_resolve_jacobi", kernel, dim3(n_problems), dim3(kWideThreads), bytes, st, d_prob, pp, std::max(max_n, 1));
+    return OVS_OK;
+}
+
+// serial_only: the single-wave kernels (the repetition after a workgroup-wide kernel reported kResolveOverflow)
+int launch_resolve(const proj_problem* d_prob, int n_problems, int max_n, int max_nq, const proj_params& pp, hipStream_t st, bool serial_only = false) {
+    if (!serial_only && jacobi_resolve_applies(pp, n_problems, max_n, max_nq)) {
+        if (pp.kind == kFrameLms) {
+            return launch_resolve_jacobi(k_proj_resolve_jacobi<kFrameLms>, d_prob, n_problems, max_n, max_nq, pp, st);
+        }
+        return launch_resolve_jacobi(k_proj_resolve_jacobi<kRange>, d_prob, n_problems, max_n, max_nq, pp, st);
+    }
+    if (!serial_only && wide_resolve_applies(pp, n_problems, max_n, max_nq)) {
         if (pp.kind == kCurrLast) {
             return launch_resolve_wide(k_proj_resolve_wide<kCurrLast>, d_prob, n_problems, max_n, max_nq, pp, st);
         }
@@ -1845,7 +2206,7 @@ size_t frame_bytes(const ovs_frame_view* f) {
 
 // Carves the device buffers of a host frame view and stages the caller's arrays for the upload.
 struct staged_frame {
-    frame_dev dev;
+    frame_dev dev{}; // every field the staging does not set is zero (n_entries_plus1 = 0: a grid)
     u32* d_items = nullptr;
 };
 
@@ -1877,6 +2238,7 @@ void stage_frame(const ovs_frame_view* f, carver& cv, host_stager& hs, staged_fr
     out.cell_start = d_cell_start;
     out.g_entry = d_entry;
     out.g_desc = d_gdesc;
+    out.n_entries_plus1 = 0;
     out.inv_level_sigma_sq = nullptr;
     sf_out.d_items = d_items;
 }
@@ -2019,6 +2381,17 @@ int run_projection(const ovs_frame_view* frm, const ovs_proj_queries* q, const u
     hs.get(&num, d_num, 4);
     hs.get(&err, d_err, 4);
     OVS_HIP(hs.download());
+    if (err == kResolveOverflow) {
+        // a query needed more candidate rows than the workgroup-wide kernel keeps: the single-wave kernel
+        // resolves the same lists
+        OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
+        OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
+        OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
+        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st, true)) != OVS_OK) {
+            return rc;
+        }
+        OVS_HIP(hs.download());
+    }
     if (err != 0) {
         return ovs::fail(err, "scale level or rotation bin out of range");
     }
@@ -2194,6 +2567,7 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
         P.frm.grid.num_cols = P.frm.grid.num_rows = 1;
         P.frm.g_entry = d_entry;
         P.frm.g_desc = d_gdesc;
+        P.frm.n_entries_plus1 = static_cast<int>(ne) + 1;
         P.q.n = static_cast<int>(nq);
         P.q.angle = d_ang;
         P.q.desc = d_qdesc;
@@ -2217,7 +2591,7 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
         if (nq) {
             launch_candidates(static_cast<int>(nq), 1, d_prob, pp, st);
         }
-        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(n), static_cast<int>(nq), pp, st)) != OVS_OK) {
+        if ((rc = launch_resolve(d_prob, 1, static_cast<int>(std::max(n, ne)), static_cast<int>(nq), pp, st)) != OVS_OK) {
             return rc;
         }
         OVS_HIP(hipGetLastError());
@@ -2236,6 +2610,15 @@ int run_ranged(const ranged_problem& rp, int32_t* matched_out, int32_t* acc_out,
             hs.get(amb.data(), d_amb, amb.size() * 4);
         }
         OVS_HIP(hs.download());
+        if (err == kResolveOverflow) {
+            OVS_HIP(hipMemsetAsync(d_err, 0, 4, st));
+            OVS_HIP(hipMemsetAsync(d_num, 0, 4, st));
+            OVS_HIP(hipMemsetAsync(d_acc, 0xFF, nq * 4, st));
+            if ((rc = launch_resolve(d_prob, 1, static_cast<int>(std::max(n, ne)), static_cast<int>(nq), pp, st, true)) != OVS_OK) {
+                return rc;
+            }
+            OVS_HIP(hs.download());
+        }
         if (err != 0) {
             return ovs::fail(err, "rotation bin out of range");
         }
