@@ -190,6 +190,38 @@ def test_greedy_conflicts_exhaust_candidate_lists():
     run_both("match_frame_and_landmarks", (view.ref(), q.ref(), None, 20.0, 0.8), n)
 
 
+def test_chain_of_forty_queries_that_push_each_other_on():
+    """Forty keypoints on one spot, equally distant from 64 identical queries, octaves alternating so that
+    the same-octave ratio test of match_frame_and_landmarks never applies (projection.cc:69-73): query k takes
+    keypoint k, and from query 8 on every listed candidate is held, from query 16 on the next eight too, ...
+    A resolver that keeps a bounded number of candidates per query has to fetch more, five times over."""
+    n, nq = 40, 64
+    rng = np.random.default_rng(52)
+    kps = np.zeros(n, dtype=A.KEYPOINT_DTYPE)
+    kps["x"], kps["y"] = 600.5, 200.5
+    kps["octave"] = np.arange(n) % 2
+    kps["angle"] = rng.uniform(0, 360, n)
+    base = rng.integers(0, 256, 32, dtype=np.uint8)
+    desc = np.tile(base, (n, 1))
+    for i in range(n):
+        for b in rng.choice(256, 6, replace=False):
+            desc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    xy = np.tile(np.array([[600.0, 200.0]], dtype=np.float32), (nq, 1))
+    sl = np.ones(nq, dtype=np.int32)
+    qd = np.tile(base, (nq, 1))
+    view = A.make_frame_view(kps, desc, SF, GRID)
+    q = A.make_proj_queries(xy, sl, qd, angle=np.zeros(nq, np.float32))
+    m, num = run_both("match_frame_and_landmarks", (view.ref(), q.ref(), None, 20.0, 0.8), n)
+    assert num == n and m.tolist() == list(range(n))
+    m, num = run_both("match_current_and_last_frames", (view.ref(), q.ref(), None, 20.0, A.DIR_NONE, 8, 0.9, 0), n)
+    assert num == n and m.tolist() == list(range(n))
+    # every other query is a landmark without observations: it takes a keypoint without holding it
+    has_obs = (np.arange(nq) % 2).astype(np.uint8)
+    q2 = A.make_proj_queries(xy, sl, qd, angle=np.zeros(nq, np.float32), has_observation=has_obs)
+    run_both("match_frame_and_landmarks", (view.ref(), q2.ref(), None, 20.0, 0.8), n)
+    run_both("match_current_and_last_frames", (view.ref(), q2.ref(), None, 20.0, A.DIR_NONE, 8, 0.9, 0), n)
+
+
 @pytest.mark.parametrize("kind", ["current_and_last", "frame_and_landmarks", "sim3"])
 def test_searched_frame_beyond_the_lds_plan(kind):
     """More keypoints in the searched frame (24 000) than the resolve kernel can keep per-keypoint state

@@ -1,0 +1,55 @@
+"""The matcher translation units of the HIP library -- host code and kernels, unchanged -- compiled for the
+host against a stand-in for the HIP runtime (tools/emu/hip_host: kernels run as fibers, wave operations as
+exchanges between the lanes that reach them, device memory and dynamic LDS surrounded by inaccessible address
+space) and called through the same C ABI with the inputs of the GPU parity tests, in smaller sizes: results
+must be the oracle's, and an access through a wild index ends the run with a report.  No GPU is involved:
+this checks the index arithmetic and the data flow of the source that is also compiled for the device --
+which kernel a call selects, what it reads and writes, that every workgroup barrier is reached, that the result
+does not depend on the order in which threads run between synchronisation points -- not the timing and not the
+hardware's memory model; the GPU parity tests stay the gate for the product.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "tests", "emulated_cases.py")
+
+
+def run(group, env=None):
+    e = dict(os.environ)
+    for k in ("OVS_RESOLVE", "OVS_GROUP_LIVE", "EMU_SHUFFLE", "EMU_REVERSE", "EMU_STRICT_LDS"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, DRIVER, group], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    m = re.search(r"^kernels: (.*)$", r.stdout, re.M)
+    assert m and re.search(r"^OK \d+$", r.stdout, re.M), r.stdout[-2000:]
+    return {kv.split("=")[0]: int(kv.split("=")[1]) for kv in m.group(1).split()}
+
+
+def test_matchers_with_the_default_kernel_choice():
+    # a call with one problem: grid build, candidates with 16 lanes per query, the workgroup-wide resolve kernel
+    # for the matchers without a ratio test, the single-wave kernel for the others
+    k = run("matchers", {"EMU_STRICT_LDS": "1"})
+    assert k["k_proj_resolve_wide"] > 0 and k["k_proj_resolve"] > 0 and k["k_proj_candidates"] > 0 and k["k_grid_build"] > 0
+    assert "k_proj_resolve_jacobi" not in k
+
+
+def test_matchers_with_the_ratio_test_on_the_workgroup_wide_kernel():
+    k = run("matchers", {"OVS_RESOLVE": "wide", "EMU_STRICT_LDS": "1", "EMU_SHUFFLE": "11"})
+    assert k["k_proj_resolve_jacobi"] > 0 and k["k_proj_resolve_wide"] > 0
+
+
+def test_matchers_on_the_single_wave_kernel_with_threads_in_reverse_order():
+    # the batch configuration: eight lanes per query, one wave per problem
+    k = run("matchers", {"OVS_RESOLVE": "wave", "OVS_GROUP_LIVE": "8", "EMU_REVERSE": "1"})
+    assert "k_proj_resolve_wide" not in k and "k_proj_resolve_jacobi" not in k and k["k_proj_resolve"] > 0
+
+
+def test_bow_transform_kernels():
+    k = run("bow", {"EMU_SHUFFLE": "3"})
+    assert k["k_bow_descend"] > 0 and k["k_bow_rank"] > 0 and k["k_bow_compact"] > 0
