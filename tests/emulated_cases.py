@@ -1,4 +1,4 @@
-"""Driver of tests/test_matchers_emulated.py (run as a script in a process of its own, because the library
+"""Driver of tests/test_library_emulated.py (run as a script in a process of its own, because the library
 reads OVS_RESOLVE once per process): points openvslam_amd._lib at the library built for the host
 (tools/emu) and calls the parity checks of the GPU test files with small inputs.  Prints the kernels that
 were launched and `OK <n>`.
@@ -17,7 +17,12 @@ L = host_lib.install()
 
 from openvslam_amd import _abi as A  # noqa: E402
 from openvslam_amd import _lib  # noqa: E402
+import test_area_matcher as TA  # noqa: E402
 import test_fuse_matcher as TF  # noqa: E402
+import test_gpu_extractor as TE  # noqa: E402
+import test_gpu_hamming_knn as TK  # noqa: E402
+import test_gpu_stereo as TS  # noqa: E402
+import test_landmark_descriptor as TL  # noqa: E402
 import test_gpu_bow as TB  # noqa: E402
 import test_gpu_projection as TP  # noqa: E402
 import test_gpu_robust_bow as TR  # noqa: E402
@@ -58,12 +63,36 @@ def bow():
     yield TB.test_wide_nodes_and_small_inputs
 
 
+def extract():
+    yield lambda: TE.test_extract_matches_oracle(640, 480, 1000)
+    yield lambda: TE.test_blur_borders_every_width_class(259, 0)
+    yield lambda: TE.test_blur_borders_every_width_class(514, 1)
+    yield TE.test_extract_low_texture_uses_min_threshold
+    yield TE.test_extract_with_rectangle_masks
+    yield TE.test_extract_portrait
+    yield TE.test_extract_from_strided_host_buffers
+    yield lambda: TE.test_extract_large_quota_per_level(2, 2500, 640, 480)
+    yield lambda: TS.test_stereo_compute_matches_oracle(640, 480, 800, 4)
+
+
+def others():
+    yield lambda: TK.test_hamming_pairs(4097)
+    yield lambda: TK.test_hamming_matrix(257, 129)
+    yield lambda: TK.test_get_keypoints_in_cell(1, 2000, 500)
+    yield lambda: TK.test_desc_db_search(3, 4097, 65)
+    yield lambda: TS.test_match_for_triangulation(2, 800, 20, 0)
+    yield TS.test_match_for_triangulation_borderline_epipolar_decisions
+    yield lambda: TA.test_gpu_contested_keypoints(2, 1500, 40, 0, 1.0, 200)
+    yield TA.test_gpu_closer_keypoint_takes_over
+    yield lambda: TL.test_gpu_matches_oracle(2, [300, 1, 1000, 2])
+
+
 def main():
     group = sys.argv[1] if len(sys.argv) > 1 else "matchers"
     L.ovs_timing_reset()
     L.ovs_timing_enable(1)
     n = 0
-    for case in {"matchers": matchers, "bow": bow}[group]():
+    for case in {"matchers": matchers, "bow": bow, "extract": extract, "others": others}[group]():
         case()
         n += 1
     L.ovs_timing_enable(0)

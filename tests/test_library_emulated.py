@@ -1,4 +1,4 @@
-"""The matcher translation units of the HIP library -- host code and kernels, unchanged -- compiled for the
+"""The translation units of the HIP library -- host code and kernels, unchanged -- compiled for the
 host against a stand-in for the HIP runtime (tools/emu/hip_host: kernels run as fibers, wave operations as
 exchanges between the lanes that reach them, device memory and dynamic LDS surrounded by inaccessible address
 space) and called through the same C ABI with the inputs of the GPU parity tests, in smaller sizes: results
@@ -53,3 +53,17 @@ def test_matchers_on_the_single_wave_kernel_with_threads_in_reverse_order():
 def test_bow_transform_kernels():
     k = run("bow", {"EMU_SHUFFLE": "3"})
     assert k["k_bow_descend"] > 0 and k["k_bow_rank"] > 0 and k["k_bow_compact"] > 0
+
+
+def test_extractor_and_stereo_kernels():
+    # resize, FAST cells, quadtree (LDS and workspace instances), blur (both coefficient sets), orientation +
+    # descriptors, the stereo matcher on the extractor's pyramids
+    k = run("extract")
+    for name in ("k_resize_rows", "k_fast_cells", "k_quadtree", "k_gauss7", "k_orient_desc", "k_stereo_match"):
+        assert k[name] > 0, name
+
+
+def test_hamming_database_triangulation_area_and_landmark_kernels():
+    k = run("others", {"EMU_REVERSE": "1"})
+    for name in ("k_hamming_pairs", "k_hamming_matrix", "k_knn2_partial", "k_window_list", "k_landmark_median", "k_proj_resolve"):
+        assert k[name] > 0, name

@@ -46,6 +46,9 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __shared__ static
+#define __constant__ static
+#define __align__(n) __attribute__((aligned(n)))
+#define HIP_SYMBOL(x) (&(x))
 
 // ---- types ----------------------------------------------------------------------------------------
 enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorInvalidDevice = 101, hipErrorNotReady = 600 };
@@ -322,7 +325,9 @@ inline void run_workgroup(int nt, idx3 block_id) {
             const int i = order[ii];
             if (g_fibers[i].st == READY) {
                 g_cur = i;
-                threadIdx.x = (unsigned)i;
+                threadIdx.x = (unsigned)i % blockDim.x;
+                threadIdx.y = ((unsigned)i / blockDim.x) % blockDim.y;
+                threadIdx.z = (unsigned)i / (blockDim.x * blockDim.y);
                 swapcontext(&g_sched, &g_fibers[i].ctx);
                 ran = true;
                 done += g_fibers[i].st == DONE;
@@ -404,9 +409,10 @@ struct body_holder {
 template <typename... KArgs, typename... Args>
 inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args... args) {
     std::lock_guard<std::recursive_mutex> g(big_lock());
-    if (block.y != 1 || block.z != 1 || block.x == 0 || block.x > 1024) {
+    const unsigned long long block_threads = (unsigned long long)block.x * block.y * block.z;
+    if (block_threads == 0 || block_threads > 1024) {
         g_kernel = name;
-        die("unsupported block shape");
+        die("a workgroup has 1 to 1024 threads");
     }
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) {
         g_kernel = name;
@@ -447,7 +453,7 @@ inline void launch(const char* name, void (*kernel)(KArgs...), dim3 grid, dim3 b
                 b.x = bx;
                 b.y = by;
                 b.z = bz;
-                run_workgroup((int)block.x, b);
+                run_workgroup((int)block_threads, b);
             }
         }
     }
@@ -607,7 +613,7 @@ constexpr long long site_of(const char* file, int line) {
 #define __builtin_amdgcn_readfirstlane(v) emu::readfirstlane(EMU_SITE, (v))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp(EMU_SITE, (old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_wave_barrier() emu::wave_barrier(EMU_SITE)
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_s_barrier() emu::barrier()
 #define __threadfence() ((void)0)
 #define __threadfence_block() ((void)0)
@@ -617,6 +623,13 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline unsigned __brev(unsigned v) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; ++i) {
+        r |= ((v >> i) & 1u) << (31 - i);
+    }
+    return r;
+}
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 static inline unsigned __float_as_uint(float f) { return emu::from_bits<unsigned>(emu::to_bits(f)); }
@@ -649,6 +662,137 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((un
 static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8 * (sh & 3)));
 }
+
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (sh & 31));
+}
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline int __mul24(int a, int b) { return (int)((unsigned)((a << 8) >> 8) * (unsigned)((b << 8) >> 8)); }
+// v_perm_b32 D, S0 = hi, S1 = lo, selector: bytes 0-3 of the selector pick, for result bytes 0-3, byte 0-3 of lo,
+// 4-7 = byte 0-3 of hi, 8-11 = the sign of lo byte 1 / lo byte 3 / hi byte 1 / hi byte 3 replicated, 12 = 0x00, 13+ = 0xFF
+static inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel) {
+    const unsigned long long both = ((unsigned long long)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const unsigned s = (sel >> (8 * i)) & 0xFF;
+        unsigned b;
+        if (s <= 7) {
+            b = (unsigned)(both >> (8 * s)) & 0xFF;
+        }
+        else if (s <= 11) {
+            const int bit = s == 8 ? 15 : (s == 9 ? 31 : (s == 10 ? 47 : 63));
+            b = ((both >> bit) & 1) ? 0xFF : 0x00;
+        }
+        else {
+            b = s == 12 ? 0x00 : 0xFF;
+        }
+        r |= b << (8 * i);
+    }
+    return r;
+}
+static inline unsigned __builtin_amdgcn_udot4(unsigned a, unsigned b, unsigned c, bool clamp) {
+    unsigned long long acc = c;
+    for (int i = 0; i < 4; ++i) {
+        acc += (unsigned long long)((a >> (8 * i)) & 0xFF) * ((b >> (8 * i)) & 0xFF);
+    }
+    return clamp && acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
+}
+static inline int __builtin_amdgcn_sdot4(int a, int b, int c, bool clamp) {
+    long long acc = c;
+    for (int i = 0; i < 4; ++i) {
+        acc += (long long)(signed char)((unsigned)a >> (8 * i)) * (signed char)((unsigned)b >> (8 * i));
+    }
+    if (clamp) {
+        acc = acc > 2147483647ll ? 2147483647ll : (acc < -2147483648ll ? -2147483648ll : acc);
+    }
+    return (int)acc;
+}
+
+#if defined(__clang__)
+typedef unsigned short emu_u16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int emu_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
+typedef int emu_i32x4 __attribute__((ext_vector_type(4)));
+static inline unsigned __builtin_amdgcn_udot2(emu_u16x2 a, emu_u16x2 b, unsigned c, bool clamp) {
+    const unsigned long long acc = (unsigned long long)c + (unsigned long long)a.x * b.x + (unsigned long long)a.y * b.y;
+    return clamp && acc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)acc;
+}
+
+// Buffer resources: a base address and a number of bytes; a raw (unstrided) access is range-checked per dword,
+// a load out of range returns 0 and a store out of range is dropped, as on the hardware.  In-range addresses
+// still have to lie in accessible memory.
+struct __amdgpu_buffer_rsrc_t {
+    unsigned char* base;
+    unsigned num_records;
+};
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void* p, short stride, int num, int) {
+    if (stride != 0) {
+        emu::die("strided buffer resources are not emulated");
+    }
+    return __amdgpu_buffer_rsrc_t{static_cast<unsigned char*>(p), (unsigned)num};
+}
+static inline unsigned emu_buffer_dword(const __amdgpu_buffer_rsrc_t& r, unsigned off) {
+    if ((unsigned long long)off + 4 > r.num_records) {
+        return 0;
+    }
+    unsigned v;
+    memcpy(&v, r.base + off, 4);
+    return v;
+}
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    return emu_buffer_dword(r, voff + soff);
+}
+static inline emu_u32x3 __builtin_amdgcn_raw_buffer_load_b96(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    const unsigned o = voff + soff;
+    return emu_u32x3{emu_buffer_dword(r, o), emu_buffer_dword(r, o + 4), emu_buffer_dword(r, o + 8)};
+}
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    const unsigned o = voff + soff;
+    return emu_u32x4{emu_buffer_dword(r, o), emu_buffer_dword(r, o + 4), emu_buffer_dword(r, o + 8), emu_buffer_dword(r, o + 12)};
+}
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, int) {
+    const unsigned o = voff + soff;
+    if ((unsigned long long)o + 4 <= r.num_records) {
+        memcpy(r.base + o, &v, 4);
+    }
+}
+
+// v_mfma_i32_16x16x64_i8: D (16 x 16) = A (16 x 64) * B (64 x 16) + C.  Lane l holds row l % 16 of A and
+// column l % 16 of B, sixteen consecutive k each (k = 16 * (l / 16) + byte), and rows 4 * (l / 16) + r of
+// column l % 16 of C / D.  (Which sixteen k a lane holds is the same for A and B, so a sum over k does not
+// depend on it.)  Two exchanges: operands, then "everybody has read them".
+namespace emu {
+struct mfma_ops {
+    emu_i32x4 a, b;
+};
+inline emu_i32x4 mfma_i32_16x16x64_i8(long long site, emu_i32x4 a, emu_i32x4 b, emu_i32x4 c) {
+    mfma_ops mine{a, b};
+    const snapshot& s = exchange(site, (u64)(uintptr_t)&mine);
+    if (s.active != ~0ull) {
+        die("MFMA with inactive lanes");
+    }
+    const int me = lane_id(), col = me & 15, rg = me >> 4;
+    emu_i32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        int acc = 0;
+        for (int g = 0; g < 4; ++g) {
+            const mfma_ops* pa = reinterpret_cast<const mfma_ops*>((uintptr_t)s.val[16 * g + row]);
+            const mfma_ops* pb = reinterpret_cast<const mfma_ops*>((uintptr_t)s.val[16 * g + col]);
+            const signed char* ab = reinterpret_cast<const signed char*>(&pa->a);
+            const signed char* bb = reinterpret_cast<const signed char*>(&pb->b);
+            for (int k = 0; k < 16; ++k) {
+                acc += (int)ab[k] * (int)bb[k];
+            }
+        }
+        d[r] += acc;
+    }
+    (void)exchange(site | (1ll << 30), 0);
+    return d;
+}
+} // namespace emu
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu::mfma_i32_16x16x64_i8(EMU_SITE, (a), (b), (c))
+#endif
 
 #define EMU_MINMAX(T)                                      \
     static inline T min(T a, T b) { return b < a ? b : a; } \
@@ -787,6 +931,32 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = (float)(b->t - a->t);
+    return hipSuccess;
+}
+constexpr unsigned hipEventDisableTiming = 2;
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipGetSymbolAddress(void** p, const void* symbol) {
+    *p = const_cast<void*>(symbol);
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpyToSymbol(const void* symbol, const void* src, size_t bytes, size_t offset = 0, hipMemcpyKind = hipMemcpyHostToDevice) {
+    std::lock_guard<std::recursive_mutex> g(emu::big_lock());
+    memcpy(static_cast<char*>(const_cast<void*>(symbol)) + offset, src, bytes);
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpy2D(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+    std::lock_guard<std::recursive_mutex> g(emu::big_lock());
+    for (size_t y = 0; y < height; ++y) {
+        memmove(static_cast<char*>(dst) + y * dpitch, static_cast<const char*>(src) + y * spitch, width);
+    }
+    return hipSuccess;
+}
+static inline hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t) {
+    return hipMemcpy2D(dst, dpitch, src, spitch, width, height, k);
+}
+static inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+    *free_b = *total_b = (size_t)256 << 30;
     return hipSuccess;
 }
 static inline hipError_t hipFuncSetAttribute(const void* fn, hipFuncAttribute attr, int value) {

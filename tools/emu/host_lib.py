@@ -61,6 +61,47 @@ def install(units=None):
     return lib
 
 
+def torch_on_host():
+    """Tests keep arrays for the device-pointer entry points in torch tensors on "cuda".  Under emulation device
+    memory is host memory, so a "cuda" device becomes the CPU and the handful of torch.cuda calls the tests make
+    (streams, synchronisation) become no-ops: the pointers the library gets are then plain host pointers."""
+    import contextlib
+
+    import torch
+
+    real_device = torch.device
+
+    class FakeStream:
+        _next = 0x1000
+
+        def __init__(self, *a, **k):
+            FakeStream._next += 0x10
+            self.cuda_stream = FakeStream._next
+
+        def wait_stream(self, other):
+            pass
+
+        def synchronize(self):
+            pass
+
+    class NullStream(FakeStream):
+        def __init__(self):
+            self.cuda_stream = 0
+
+    def device(*a, **k):
+        if a and (a[0] == "cuda" or (isinstance(a[0], str) and a[0].startswith("cuda"))):
+            return real_device("cpu")
+        return real_device(*a, **k)
+
+    torch.device = device
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: NullStream()
+    torch.cuda.Stream = FakeStream
+    torch.cuda.stream = lambda s: contextlib.nullcontext()
+    torch.cuda.mem_get_info = lambda *a, **k: (256 << 30, 256 << 30)
+
+
 def pytest_configure(config):
     units = os.environ.get("OVS_EMU_UNITS")
     install(units.split(",") if units else None)
+    torch_on_host()
