@@ -2675,7 +2675,7 @@ int build_bow_queries(const ovs_bow_feat_vec* qv, const uint8_t* q_descs, const 
         if (qv->node_ids[a] == cv_->node_ids[b]) {
             for (u32 k = qv->offsets[a]; k < qv->offsets[a + 1]; ++k) {
                 const u32 idx = qv->indices[k];
-                if (static_cast<int>(idx) >= nq_kp) {
+                if (idx >= static_cast<u32>(nq_kp)) {
                     return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keypoint index out of range");
                 }
                 if (q_valid && !q_valid[idx]) {
@@ -2699,7 +2699,7 @@ int build_bow_queries(const ovs_bow_feat_vec* qv, const uint8_t* q_descs, const 
     }
     const u32 total = cv_->num_nodes ? cv_->offsets[cv_->num_nodes] : 0;
     for (u32 k = 0; k < total; ++k) {
-        if (static_cast<int>(cv_->indices[k]) >= n_cand) {
+        if (cv_->indices[k] >= static_cast<u32>(n_cand)) {
             return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keypoint index out of range");
         }
     }
@@ -3109,7 +3109,7 @@ int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
             if (vec_1->node_ids[a] == vec_2->node_ids[b]) {
                 for (u32 k = vec_1->offsets[a]; k < vec_1->offsets[a + 1]; ++k) {
                     const u32 idx_1 = vec_1->indices[k];
-                    if (static_cast<int>(idx_1) >= n1) {
+                    if (idx_1 >= static_cast<u32>(n1)) {
                         return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
                     }
                     if (has_lm_1 && has_lm_1[idx_1]) {
@@ -3145,7 +3145,7 @@ int ovs_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
     }
     const u32 n_entries = vec_2->num_nodes ? vec_2->offsets[vec_2->num_nodes] : 0;
     for (u32 k = 0; k < n_entries; ++k) {
-        if (static_cast<int>(vec_2->indices[k]) >= n2) {
+        if (vec_2->indices[k] >= static_cast<u32>(n2)) {
             return ovs::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
         }
     }

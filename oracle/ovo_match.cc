@@ -1024,7 +1024,7 @@ int ovo_bow_match_frame_and_keyframe(const ovs_bow_feat_vec* kf_vec, const uint8
         if (kf_vec->node_ids[keyfrm_itr] == frm_vec->node_ids[frm_itr]) {
             for (uint32_t a = kf_vec->offsets[keyfrm_itr]; a < kf_vec->offsets[keyfrm_itr + 1]; ++a) {
                 const auto keyfrm_idx = kf_vec->indices[a];
-                if (static_cast<int>(keyfrm_idx) >= n_kf) {
+                if (keyfrm_idx >= static_cast<unsigned int>(n_kf)) {
                     return ovo::fail(OVS_ERR_OUT_OF_RANGE, "keyframe index out of range");
                 }
                 if (valid_kf && !valid_kf[keyfrm_idx]) {
@@ -1038,7 +1038,7 @@ int ovo_bow_match_frame_and_keyframe(const ovs_bow_feat_vec* kf_vec, const uint8
 
                 for (uint32_t b = frm_vec->offsets[frm_itr]; b < frm_vec->offsets[frm_itr + 1]; ++b) {
                     const auto frm_idx = frm_vec->indices[b];
-                    if (static_cast<int>(frm_idx) >= n_frm) {
+                    if (frm_idx >= static_cast<unsigned int>(n_frm)) {
                         return ovo::fail(OVS_ERR_OUT_OF_RANGE, "frame index out of range");
                     }
                     if (0 <= matched_kf_idx_in_frm[frm_idx]) {
@@ -1111,7 +1111,7 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
         if (vec_1->node_ids[itr_1] == vec_2->node_ids[itr_2]) {
             for (uint32_t a = vec_1->offsets[itr_1]; a < vec_1->offsets[itr_1 + 1]; ++a) {
                 const auto idx_1 = vec_1->indices[a];
-                if (static_cast<int>(idx_1) >= n1) {
+                if (idx_1 >= static_cast<unsigned int>(n1)) {
                     return ovo::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
                 }
                 if (valid_1 && !valid_1[idx_1]) {
@@ -1125,7 +1125,7 @@ int ovo_bow_match_keyframes(const ovs_bow_feat_vec* vec_1, const uint8_t* descs_
 
                 for (uint32_t b = vec_2->offsets[itr_2]; b < vec_2->offsets[itr_2 + 1]; ++b) {
                     const auto idx_2 = vec_2->indices[b];
-                    if (static_cast<int>(idx_2) >= n2) {
+                    if (idx_2 >= static_cast<unsigned int>(n2)) {
                         return ovo::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
                     }
                     if (valid_2 && !valid_2[idx_2]) {
@@ -1227,7 +1227,7 @@ int ovo_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
         if (vec_1->node_ids[itr_1] == vec_2->node_ids[itr_2]) {
             for (uint32_t a = vec_1->offsets[itr_1]; a < vec_1->offsets[itr_1 + 1]; ++a) {
                 const auto idx_1 = vec_1->indices[a];
-                if (static_cast<int>(idx_1) >= n1) {
+                if (idx_1 >= static_cast<unsigned int>(n1)) {
                     return ovo::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 1 index out of range");
                 }
                 if (has_lm_1 && has_lm_1[idx_1]) {
@@ -1246,7 +1246,7 @@ int ovo_match_for_triangulation(const ovs_bow_feat_vec* vec_1, const uint8_t* de
 
                 for (uint32_t b = vec_2->offsets[itr_2]; b < vec_2->offsets[itr_2 + 1]; ++b) {
                     const auto idx_2 = vec_2->indices[b];
-                    if (static_cast<int>(idx_2) >= n2) {
+                    if (idx_2 >= static_cast<unsigned int>(n2)) {
                         return ovo::fail(OVS_ERR_OUT_OF_RANGE, "keyframe 2 index out of range");
                     }
                     if (has_lm_2 && has_lm_2[idx_2]) {

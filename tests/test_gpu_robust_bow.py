@@ -136,11 +136,14 @@ def test_bow_out_of_range_index():
     d = np.zeros((4, 32), dtype=np.uint8)
     a = np.zeros(4, dtype=np.float32)
     v_ok = A.make_bow_feat_vec({1: [0, 1], 2: [2, 3]})
-    v_bad = A.make_bow_feat_vec({1: [0, 9]})
     m = np.zeros(4, dtype=np.int32)
     num = C.c_uint32(0)
-    for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
-        rc = getattr(lib_, prefix + "bow_match_frame_and_keyframe")(v_bad.ref(), A.ptr(d, A.u8p), A.ptr(a, A.f32p), None, 4,
-                                                                    v_ok.ref(), A.ptr(d, A.u8p), A.ptr(a, A.f32p), 4,
-                                                                    0.75, 0, A.ptr(m, A.i32p), C.byref(num), *extra)
-        assert rc == A.OVS_ERR_OUT_OF_RANGE
+    # 9: past the four keypoints; 2^31 and 2^32 - 1: negative when read as a signed int
+    for bad in (9, 4, 1 << 31, (1 << 32) - 1):
+        v_bad = A.make_bow_feat_vec({1: [0, bad]})
+        for lib_, prefix, extra in ((_lib.lib(), "ovs_", (0,)), (oracle.lib(), "ovo_", ())):
+            for first, second in ((v_bad, v_ok), (v_ok, v_bad)):
+                rc = getattr(lib_, prefix + "bow_match_frame_and_keyframe")(first.ref(), A.ptr(d, A.u8p), A.ptr(a, A.f32p), None, 4,
+                                                                            second.ref(), A.ptr(d, A.u8p), A.ptr(a, A.f32p), 4,
+                                                                            0.75, 0, A.ptr(m, A.i32p), C.byref(num), *extra)
+                assert rc == A.OVS_ERR_OUT_OF_RANGE, (prefix, bad)

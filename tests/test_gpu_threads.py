@@ -5,6 +5,7 @@ extractor (data/frame.cc:64-67).  ctypes releases the GIL around every call, so 
 inside the library together; every result of every iteration must equal the oracle's, which is computed
 beforehand on one thread."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -19,7 +20,7 @@ from test_gpu_robust_bow import clustered_sets, two_sets
 
 pytestmark = pytest.mark.gpu
 
-ROUNDS = 20
+ROUNDS = int(os.environ.get("OVS_TEST_THREAD_ROUNDS", "20"))  # fewer when the library runs on the host emulator
 
 
 def _oracle_call(name, args, n_out, shape=None):

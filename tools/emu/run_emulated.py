@@ -22,11 +22,16 @@ SIZED_FOR_THE_DEVICE = [
     "tests/test_gpu_hamming_knn.py::test_full_size_database_shards_find_planted_neighbours",
     "tests/test_undistort.py::test_gpu_full_size_batch_properties",
     "tests/test_gpu_projection.py::test_searched_frame_beyond_the_lds_plan",
+    "tests/test_zz_no_alloc.py::test_noalloc_search_equals_the_allocating_search",
+    # torch.distributed on the device (dist.py keeps its tensors on the GPU and all-gathers over RCCL)
+    "tests/test_gpu_hamming_knn.py::test_sharded_search_equals_whole_database",
+    "tests/test_gpu_hamming_knn.py::test_sharded_search_device_path_over_rccl_world_of_one",
     "tests/test_cpp_shim.py::test_shim_extract_and_match_on_gpu",
     "tests/test_cpp_shim.py::test_shim_from_four_threads_on_gpu",
 ]
 
 if __name__ == "__main__":
+    os.environ.setdefault("OVS_TEST_THREAD_ROUNDS", "2")
     args = sys.argv[1:]
     extra = []
     if "--full-size" in args:
