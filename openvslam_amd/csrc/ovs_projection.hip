@@ -2045,17 +2045,16 @@ int launch_resolve_wide(Kernel kernel, const proj_problem* d_prob, int n_problem
     return OVS_OK;
 }
 
-// The ratio-test matchers on the workgroup-wide kernel that rebuilds its words every round.  Opt-in
-// (OVS_RESOLVE=wide): the kernel passed the projection / brute-force / BoW parity tests on the device, but its
-// last change (and the change of frame staging that goes with it) has not been run there since, so the
-// single-wave kernel stays the default for these matchers.
+// The ratio-test matchers on the workgroup-wide kernel that rebuilds its words every round: calls with a few
+// problems, as for k_proj_resolve_wide (one 2000-query frame: 0.032 ms against 0.115 ms on a single wave).
+// OVS_RESOLVE=wave / wide forces one of the two.
 bool jacobi_resolve_applies(const proj_params& pp, int n_problems, int max_n, int max_nq) {
-    static const bool opted_in = [] {
+    static const int forced = [] {
         const char* e = std::getenv("OVS_RESOLVE");
-        return e && std::string(e) == "wide";
+        return !e ? 0 : (std::string(e) == "wave" ? 1 : (std::string(e) == "wide" ? 2 : 0));
     }();
-    (void)n_problems;
-    return opted_in && (pp.kind == kFrameLms || pp.kind == kRange) && max_nq <= kWideThreads * kWideQueries && jacobi_lds_bytes(max_n, max_nq) <= 140 * 1024;
+    const bool few = forced == 2 || (forced == 0 && n_problems <= kWideMaxProblems);
+    return few && (pp.kind == kFrameLms || pp.kind == kRange) && max_nq <= kWideThreads * kWideQueries && jacobi_lds_bytes(max_n, max_nq) <= 140 * 1024;
 }
 
 template <typename Kernel>

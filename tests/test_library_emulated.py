@@ -32,15 +32,16 @@ def run(group, env=None):
 
 
 def test_matchers_with_the_default_kernel_choice():
-    # a call with one problem: grid build, candidates with 16 lanes per query, the workgroup-wide resolve kernel
-    # for the matchers without a ratio test, the single-wave kernel for the others
+    # a call with one problem: grid build, candidates with 16 lanes per query, the two workgroup-wide resolve kernels
+    # (without / with a ratio test); the single-wave kernel for the fuse and one-way kinds and when a query needs
+    # more rows of candidates than the workgroup-wide kernel keeps
     k = run("matchers", {"EMU_STRICT_LDS": "1"})
-    assert k["k_proj_resolve_wide"] > 0 and k["k_proj_resolve"] > 0 and k["k_proj_candidates"] > 0 and k["k_grid_build"] > 0
-    assert "k_proj_resolve_jacobi" not in k
+    assert k["k_proj_resolve_wide"] > 0 and k["k_proj_resolve_jacobi"] > 0 and k["k_proj_resolve"] > 0
+    assert k["k_proj_candidates"] > 0 and k["k_grid_build"] > 0
 
 
-def test_matchers_with_the_ratio_test_on_the_workgroup_wide_kernel():
-    k = run("matchers", {"OVS_RESOLVE": "wide", "EMU_STRICT_LDS": "1", "EMU_SHUFFLE": "11"})
+def test_matchers_with_the_workgroup_wide_kernels_forced_and_threads_shuffled():
+    k = run("matchers", {"OVS_RESOLVE": "wide", "EMU_SHUFFLE": "11"})
     assert k["k_proj_resolve_jacobi"] > 0 and k["k_proj_resolve_wide"] > 0
 
 

@@ -8,6 +8,7 @@ path at their full sizes, inputs resident in HBM, one JSON line each.
   live     one frame at a time through the host-buffer entry points                  (ms per frame)
   pre      BGR -> gray, rectification remap, histogram stretch on 256 raw 1241x376 frames (frames/s)
   post     keypoint undistortion + bearings of 256 frames x 2250 keypoints               (keypoints/s)
+  bow      BoW transform of 256 frames x 2000 descriptors, k = 10 / L = 6 vocabulary          (frames/s)
 """
 import argparse
 import ctypes as C
@@ -201,6 +202,58 @@ def post(args):
             "ms_per_step": first["ms"], "models": out}
 
 
+def bow(args):
+    """frame::compute_bow (data/frame.cc:162-170) on a resident batch: 256 frames x 2000 descriptors through a
+    synthetic vocabulary of the reference's shape (k = 10, L = 6: 1.1 M nodes, levelsup 4), per-kernel times from
+    the library's launch timing, and one frame through the host-buffer entry point; the oracle's transform of one
+    frame on one core beside it."""
+    dev = torch.device("cuda", 0)
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle
+    from openvslam_amd import bow as ovs_bow
+    from test_oracle_bow import noisy_leaf_descriptors, oracle_transform
+    L = _lib.lib()
+    voc = ovs_bow.synthetic_vocabulary(10, 6, seed=16)
+    v = ovs_bow.bow_vocabulary(voc["k"], voc["L"], voc["node_descs"], voc["child_offsets"], voc["children"], voc["word_ids"], voc["weights"])
+    n_frames, cap, n = 256, 2048, 2000
+    one = noisy_leaf_descriptors(voc, n, seed=1)
+    descs = np.zeros((n_frames, cap, 32), np.uint8)
+    rng = np.random.default_rng(2)
+    for f in range(n_frames):
+        descs[f, :n] = one[rng.permutation(n)] ^ rng.integers(0, 2, (n, 32), dtype=np.uint8)
+    d_descs = torch.from_numpy(descs).to(dev)
+    d_counts = torch.full((n_frames,), n, dtype=torch.int32, device=dev)
+    z = lambda shape, dt=torch.int32: torch.zeros(shape, dtype=dt, device=dev)  # noqa: E731
+    word_of, node_of, bow_ids, fv_ids, fv_idx = z((n_frames, cap)), z((n_frames, cap)), z((n_frames, cap)), z((n_frames, cap)), z((n_frames, cap))
+    bow_vals, fv_off, nw, nn = z((n_frames, cap), torch.float64), z((n_frames, cap + 1)), z(n_frames), z(n_frames)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        _lib.check(L.ovs_bow_transform_batch_dev(v._h, d_descs.data_ptr(), d_counts.data_ptr(), n_frames, cap, 4, word_of.data_ptr(), node_of.data_ptr(),
+                                                 bow_ids.data_ptr(), bow_vals.data_ptr(), nw.data_ptr(), fv_ids.data_ptr(), fv_off.data_ptr(), fv_idx.data_ptr(),
+                                                 nn.data_ptr(), st))
+    dt = timed(step, args.steps, args.warmup)
+    L.ovs_timing_reset()
+    L.ovs_timing_enable(1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    L.ovs_timing_enable(0)
+    kernels = {k: ms / cnt for k, (ms, cnt) in _lib.timing_report().items()}
+    t0 = time.perf_counter()
+    for _ in range(20):
+        v.transform(one, 4)
+    live_ms = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    want = oracle_transform(voc, one, 4)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    (ids, vals), fv = v.transform(one, 4)
+    same = np.array_equal(ids, want["word_ids"]) and vals.tobytes() == want["values"].tobytes() and np.array_equal(fv.keep[2], want["indices"])
+    return {"metric": "BoW transform, 256 frames x 2000 descriptors resident, k = 10 / L = 6 vocabulary (1.1 M nodes), levelsup 4", "value": n_frames / dt,
+            "unit": "frames/s", "ms_per_step": dt * 1e3, "kernel_ms_per_launch": kernels, "one_frame_host_buffers_ms": live_ms,
+            "oracle_one_frame_one_core_ms": cpu_ms, "bit_exact_vs_oracle": bool(same), "words_per_frame": int(len(ids)), "nodes_per_frame": int(fv.struct.num_nodes)}
+
+
 def live(args):
     """The live path: one frame at a time through the host-buffer entry points (image up, keypoints and
     descriptors down, synchronous), as the reference's tracking thread calls extract()."""
@@ -255,11 +308,11 @@ def live(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "post", "live", "all"])
+    ap.add_argument("workload", choices=["stereo", "equirect", "knn", "pre", "post", "live", "bow", "all"])
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     args = ap.parse_args()
-    for name in (["stereo", "equirect", "knn", "pre", "post", "live"] if args.workload == "all" else [args.workload]):
+    for name in (["stereo", "equirect", "knn", "pre", "post", "live", "bow"] if args.workload == "all" else [args.workload]):
         print(json.dumps(dict(workload=name, **globals()[name](args))))
 
 
