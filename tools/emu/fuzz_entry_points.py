@@ -377,7 +377,159 @@ def fuzz_triangulation(rng):
                                          C.byref(num), 0)
 
 
-TARGETS = {"triangulation": fuzz_triangulation, "bow": fuzz_bow, "projection": fuzz_projection, "fuse": fuzz_fuse, "area": fuzz_area, "cells": fuzz_cells, "robust": fuzz_robust, "landmarks": fuzz_landmarks,
+L._cdll.ovs_emu_guarded_alloc.restype = C.c_void_p
+L._cdll.ovs_emu_guarded_alloc.argtypes = [C.c_size_t, C.c_int]
+L._cdll.ovs_emu_guarded_free.argtypes = [C.c_void_p]
+
+
+class Guarded:
+    """Copies of numpy arrays in guarded blocks (what hipMalloc returns on this build): `dev(a)` gives an array
+    of the same shape and dtype whose memory ends at inaccessible address space; all are freed by close()."""
+
+    def __init__(self):
+        self.ptrs = []
+
+    def dev(self, a):
+        a = np.ascontiguousarray(a)
+        nbytes = max(a.nbytes, 1)
+        p = L._cdll.ovs_emu_guarded_alloc(nbytes, 0xDB)
+        assert p, "cannot reserve a guarded block"
+        self.ptrs.append(p)
+        buf = (C.c_char * nbytes).from_address(p)
+        out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+        out[...] = a
+        return out
+
+    def close(self):
+        for p in self.ptrs:
+            L._cdll.ovs_emu_guarded_free(p)
+        self.ptrs = []
+
+
+def wild_counts(rng, n_frames, cap, frac):
+    c = rng.integers(0, cap + 1, n_frames).astype(np.int64)
+    m = rng.random(n_frames) < frac
+    c[m] = rng.choice([-1, -1000, cap + 1, 2 * cap, 1 << 30, -(1 << 31)], int(m.sum()))
+    return c.astype(np.int32)
+
+
+def fuzz_batch_match_dev(rng):
+    """ovs_match_batch_current_and_last_dev on arrays that did not come from the extractor: counts outside [0, cap],
+    keypoints and reprojections anywhere.  (Device pointers are host pointers on this build.)"""
+    n_frames, cap = int(rng.choice([1, 2, 3, 9])), int(rng.choice([1, 64, 300, 1100]))
+    frac = float(rng.choice([0.0, 0.05, 0.3]))
+    k, d, _ = frame(rng, n_frames * cap, frac, stereo=False)
+    counts = wild_counts(rng, n_frames, cap, frac)
+    reproj = wild_floats(rng, rng.uniform(-50, W + 50, (n_frames, cap, 2)), frac)
+    reproj[rng.random((n_frames, cap)) < 0.1, 0] = -3e38
+    G = Guarded()
+    k, d, counts, reproj = G.dev(k), G.dev(d), G.dev(counts), G.dev(reproj)
+    matched = G.dev(np.full((n_frames, cap), -7, np.int32))
+    num = G.dev(np.zeros(n_frames, np.uint32))
+    g = grid_for(rng)
+    levels = int(rng.choice([8, 8, 1, 3]))
+    rc = L.ovs_match_batch_current_and_last_dev(k.ctypes.data, d.ctypes.data, counts.ctypes.data, n_frames, cap, reproj.ctypes.data, C.byref(g),
+                                                A.ptr(SF, A.f32p), levels, margin(rng), int(rng.integers(0, 2)), matched.ctypes.data, num.ctypes.data, 0, None)
+    G.close()
+    return rc
+
+
+def fuzz_pack_dev(rng):
+    n_frames, cap = int(rng.choice([1, 2, 17, 300])), int(rng.choice([1, 7, 64, 500]))
+    counts = wild_counts(rng, n_frames, cap, float(rng.choice([0.0, 0.3])))
+    kps = np.zeros(n_frames * cap, dtype=A.KEYPOINT_DTYPE)
+    desc = rng.integers(0, 256, (n_frames * cap, 32), dtype=np.uint8)
+    matched = rng.integers(-1, cap, n_frames * cap).astype(np.int32)
+    G = Guarded()
+    counts, kps, desc, matched = G.dev(counts), G.dev(kps), G.dev(desc), G.dev(matched)
+    offs = G.dev(np.zeros(n_frames + 1, np.int32))
+    pk, pd, pm = G.dev(np.zeros_like(kps)), G.dev(np.zeros_like(desc)), G.dev(np.zeros_like(matched))
+    which = int(rng.integers(0, 4))
+    rc = L.ovs_pack_batch_results_dev(counts.ctypes.data, n_frames, cap, kps.ctypes.data if which != 1 else None, desc.ctypes.data if which != 2 else None,
+                                      matched.ctypes.data if which != 3 else None, offs.ctypes.data, pk.ctypes.data, pd.ctypes.data, pm.ctypes.data, 0, None)
+    G.close()
+    return rc
+
+
+def fuzz_extract_stereo_dev(rng):
+    """Two batches through ovs_orb_extract_batch_dev, then ovs_stereo_compute_dev on keypoint arrays that were
+    overwritten with hostile values, and the undistortion / bearing entry points on the same arrays."""
+    w, h = int(rng.choice([64, 160, 320])), int(rng.choice([48, 120, 240]))
+    n_frames = int(rng.choice([1, 2, 3]))
+    levels = int(rng.choice([1, 2, 3]))
+    p = A.make_orb_params(int(rng.choice([50, 400])), 1.2, levels)
+    hl, hr = C.c_void_p(), C.c_void_p()
+    if L.ovs_orb_create(p.ref(), 0, C.byref(hl)) != 0 or L.ovs_orb_create(p.ref(), 0, C.byref(hr)) != 0:
+        return -1
+    cap = L.ovs_orb_keypoint_capacity(hl, w, h)
+    rc = cap if cap < 0 else 0
+    G = Guarded()
+    if cap > 0:
+        imgs = [G.dev(rng.integers(0, 256, (n_frames, h, w), dtype=np.uint8)) for _ in range(2)]
+        out = []
+        for hnd, im in zip((hl, hr), imgs):
+            kps = G.dev(np.zeros(n_frames * cap, dtype=A.KEYPOINT_DTYPE))
+            desc = G.dev(np.zeros((n_frames * cap, 32), np.uint8))
+            counts = G.dev(np.zeros(n_frames, np.int32))
+            rc = L.ovs_orb_extract_batch_dev(hnd, im.ctypes.data, n_frames, w, h, w, w * h, None, 0, kps.ctypes.data, desc.ctypes.data, counts.ctypes.data, cap, None)
+            out.append((kps, desc, counts))
+        if rc == 0:
+            frac = float(rng.choice([0.0, 0.05, 0.3]))
+            for kps, desc, counts in out:
+                m = rng.random(len(kps)) < frac
+                kps["x"][m] = rng.choice(WILD_F, int(m.sum()))
+                kps["y"][m] = rng.choice(WILD_F, int(m.sum()))
+                kps["octave"][m] = rng.choice(WILD_I, int(m.sum())).astype(np.int32)
+                counts[:] = np.where(rng.random(n_frames) < frac, wild_counts(rng, n_frames, cap, 1.0), counts)
+            (kl, dl, nl), (kr, dr, nr) = out
+            xr, dep = G.dev(np.zeros(cap, np.float32)), G.dev(np.zeros(cap, np.float32))
+            status = G.dev(np.zeros(1, np.int32))
+            f = int(rng.integers(0, n_frames))
+            rc = L.ovs_stereo_compute_dev(hl, f, hr, f, kl[f * cap:].ctypes.data, dl[f * cap:].ctypes.data, nl[f:].ctypes.data, kr[f * cap:].ctypes.data,
+                                          dr[f * cap:].ctypes.data, nr[f:].ctypes.data, cap, 40.0, 0.1, xr.ctypes.data, dep.ctypes.data, status.ctypes.data, 0, None)
+            cam = A.Camera()
+            cam.model, cam.cols, cam.rows = int(rng.integers(0, 3)), w, h
+            cam.fx, cam.fy, cam.cx, cam.cy = 300.0, 300.0, w / 2.0, h / 2.0
+            for i, v in enumerate((-0.28, 0.07, 0.0002, 0.00002, 0.0)):
+                cam.dist[i] = v
+            und = G.dev(np.zeros_like(kl))
+            bear = G.dev(np.zeros((n_frames * cap, 3), np.float64))
+            L.ovs_undistort_keypoints_dev(C.byref(cam), kl.ctypes.data, nl.ctypes.data, n_frames, cap, und.ctypes.data, bear.ctypes.data, 0, None)
+            L.ovs_convert_keypoints_to_bearings_dev(C.byref(cam), kl.ctypes.data, nl.ctypes.data, n_frames, cap, bear.ctypes.data, 0, None)
+    L.ovs_orb_destroy(hl)
+    L.ovs_orb_destroy(hr)
+    G.close()
+    return rc
+
+
+def fuzz_database_dev(rng):
+    rows = int(rng.choice([0, 1, 63, 64, 65, 4096, 4097, 9000]))
+    nq = int(rng.choice([0, 1, 63, 64, 65, 300]))
+    G = Guarded()
+    db = G.dev(rng.integers(0, int(rng.choice([2, 256])), (max(rows, 1), 32), dtype=np.uint8))
+    q = G.dev(rng.integers(0, int(rng.choice([2, 256])), (max(nq, 1), 32), dtype=np.uint8))
+    h = C.c_void_p()
+    if L.ovs_desc_db_create(0, C.byref(h)) != 0:
+        return -1
+    first = int(rng.choice([0, 5, 1 << 40]))
+    rc = L.ovs_desc_db_attach_dev(h, db.ctypes.data, rows, first)
+    out = G.dev(np.zeros(max(nq, 1), dtype=A.KNN2_DTYPE))
+    if rc == 0:
+        fn = L.ovs_desc_db_search_noalloc_dev if rng.random() < 0.5 else L.ovs_desc_db_search_dev
+        rc = fn(h, q.ctypes.data, nq, out.ctypes.data, None)
+        parts = int(rng.choice([1, 2, 5]))
+        gathered = np.zeros(parts * max(nq, 1), dtype=A.KNN2_DTYPE)
+        gathered["dist"] = rng.integers(0, 257, gathered["dist"].shape)
+        gathered["row"] = rng.integers(-1, 1 << 40, gathered["row"].shape)
+        gathered, merged = G.dev(gathered), G.dev(np.zeros(max(nq, 1), dtype=A.KNN2_DTYPE))
+        L.ovs_knn2_merge_dev(gathered.ctypes.data, parts, nq, merged.ctypes.data, None)
+    L.ovs_desc_db_destroy(h)
+    G.close()
+    return rc
+
+
+TARGETS = {"batch_match_dev": fuzz_batch_match_dev, "pack_dev": fuzz_pack_dev, "extract_stereo_dev": fuzz_extract_stereo_dev, "database_dev": fuzz_database_dev,
+           "triangulation": fuzz_triangulation, "bow": fuzz_bow, "projection": fuzz_projection, "fuse": fuzz_fuse, "area": fuzz_area, "cells": fuzz_cells, "robust": fuzz_robust, "landmarks": fuzz_landmarks,
            "stereo": fuzz_stereo, "extract": fuzz_extract}
 
 

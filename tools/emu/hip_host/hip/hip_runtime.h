@@ -968,6 +968,12 @@ static inline hipError_t hipFuncSetAttribute(const void* fn, hipFuncAttribute at
     return hipSuccess;
 }
 
+// for test programs that hand "device" arrays to the library: the same guarded blocks hipMalloc gives
+extern "C" __attribute__((used, visibility("default"))) inline void* ovs_emu_guarded_alloc(size_t bytes, int fill) {
+    return emu::guarded_alloc(bytes, "test array", fill);
+}
+extern "C" __attribute__((used, visibility("default"))) inline int ovs_emu_guarded_free(void* p) { return emu::guarded_free(p) ? 0 : -1; }
+
 #define EMU_STR2(x) #x
 #define EMU_STR(x) EMU_STR2(x)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
