@@ -301,8 +301,38 @@ def live(args):
     for _ in range(args.steps * 10):
         stereo_frame()
     stereo_ms = (time.perf_counter() - t0) / (args.steps * 10) * 1e3
+
+    # the same with the right image extracted on a second host thread, as data/frame.cc:64-67 does it
+    import queue
+    import threading
+    jobs, done = queue.Queue(), queue.Queue()
+
+    def right_worker():
+        while True:
+            if jobs.get() is None:
+                return
+            done.put(er.extract(right))
+    worker = threading.Thread(target=right_worker, daemon=True)
+    worker.start()
+
+    def stereo_frame_two_threads():
+        jobs.put(1)
+        kl, dl = el.extract(left)
+        kr, dr = done.get()
+        xr = np.empty(len(kl), np.float32)
+        dep = np.empty(len(kl), np.float32)
+        _lib.check(L.ovs_stereo_compute_resident(el._h, er._h, A.ptr(kl, A.kpp), len(kl), A.ptr(kr, A.kpp), len(kr), A.ptr(dl, A.u8p), A.ptr(dr, A.u8p),
+                                                 np.float32(fxb), np.float32(fxb / fx), A.ptr(xr, A.f32p), A.ptr(dep, A.f32p), 0))
+    for _ in range(3):
+        stereo_frame_two_threads()
+    t0 = time.perf_counter()
+    for _ in range(args.steps * 10):
+        stereo_frame_two_threads()
+    stereo2_ms = (time.perf_counter() - t0) / (args.steps * 10) * 1e3
+    jobs.put(None)
+    worker.join()
     return {"metric": "live single-frame latency, host buffers in and out", "value": 1e3 / mono_ms, "unit": "frames/s",
-            "mono_1241x376_2000kp_ms_per_frame": mono_ms, "stereo_752x480_1000kp_ms_per_pair": stereo_ms,
+            "mono_1241x376_2000kp_ms_per_frame": mono_ms, "stereo_752x480_1000kp_ms_per_pair": stereo_ms, "stereo_pair_right_image_on_a_second_host_thread_ms": stereo2_ms,
             "projection_match_ms": match_ms, "projection_queries": int(len(k0)), "projection_matches": int(num_matches)}
 
 
