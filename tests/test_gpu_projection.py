@@ -77,6 +77,8 @@ def run_both(name, args_oracle, n_out, extra_outputs=True):
                           (3, 1500, 2000, A.DIR_BACKWARD, True, True, True, 0),
                           (4, 3000, 3000, A.DIR_NONE, False, True, False, 1),
                           (5, 50, 400, A.DIR_NONE, False, True, False, 1),
+                          # 146 KB of per-keypoint and per-query words: the most the workgroup-wide resolve kernel takes
+                          (8, 5500, 2500, A.DIR_NONE, False, True, False, 1),
                           (6, 0, 10, A.DIR_NONE, False, False, False, 1),
                           (7, 300, 0, A.DIR_NONE, False, False, False, 1)])
 def test_match_current_and_last_frames(seed, n, nq, direction, stereo, cluster, occ, check):
@@ -99,7 +101,9 @@ def test_match_current_and_last_frames(seed, n, nq, direction, stereo, cluster, 
 
 
 @pytest.mark.parametrize("seed,n,nq,stereo,cluster", [(11, 2000, 4000, False, False), (12, 2500, 6000, True, True),
-                                                      (13, 100, 1000, False, True)])
+                                                      (13, 100, 1000, False, True),
+                                                      # 136 KB of words: close to the limit of the workgroup-wide kernel for ratio tests
+                                                      (14, 9000, 2000, False, True)])
 def test_match_frame_and_landmarks(seed, n, nq, stereo, cluster):
     rng = np.random.default_rng(seed)
     kps, desc, sxr = random_frame(rng, n, stereo=stereo, cluster=cluster)
