@@ -21,7 +21,7 @@ DRIVER = os.path.join(ROOT, "tests", "emulated_cases.py")
 
 def run(group, env=None):
     e = dict(os.environ)
-    for k in ("OVS_RESOLVE", "OVS_GROUP_LIVE", "EMU_SHUFFLE", "EMU_REVERSE", "EMU_STRICT_LDS"):
+    for k in ("OVS_RESOLVE", "OVS_GROUP_LIVE", "EMU_SHUFFLE", "EMU_REVERSE", "EMU_STRICT_LDS", "EMU_PREEMPT"):
         e.pop(k, None)
     e.update(env or {})
     r = subprocess.run([sys.executable, DRIVER, group], capture_output=True, text=True, env=e, timeout=900)
@@ -41,7 +41,8 @@ def test_matchers_with_the_default_kernel_choice():
 
 
 def test_matchers_with_the_workgroup_wide_kernels_forced_and_threads_shuffled():
-    k = run("matchers", {"OVS_RESOLVE": "wide", "EMU_SHUFFLE": "11"})
+    # (EMU_PREEMPT: every atomic operation is a possible switch to another thread)
+    k = run("matchers", {"OVS_RESOLVE": "wide", "EMU_SHUFFLE": "11", "EMU_PREEMPT": "11"})
     assert k["k_proj_resolve_jacobi"] > 0 and k["k_proj_resolve_wide"] > 0
 
 

@@ -14,7 +14,8 @@
 //     readlane, DPP moves and the wave barrier are built on that one primitive.
 //   * Fibers never run concurrently, so atomics are plain read-modify-writes, and everything between two
 //     synchronisation points of a thread happens at once: one legal schedule among many.  EMU_REVERSE=1 runs
-//     the threads from the last to the first, EMU_SHUFFLE=<seed> in a new random order for every stretch.
+//     the threads from the last to the first, EMU_SHUFFLE=<seed> in a new random order for every stretch,
+//     EMU_PREEMPT=<seed> makes every atomic operation a possible switch to another thread.
 //   * Dynamic LDS is a guarded block of exactly the launch's size, filled with 0xA5 before every workgroup
 //     (LDS is not zero on the hardware either); reads past it return 0 as on the hardware unless
 //     EMU_STRICT_LDS=1, writes past it always fault.  `extern __shared__ T name[];` cannot be expressed on
@@ -234,6 +235,22 @@ inline void yield_to_scheduler() { swapcontext(&g_fibers[g_cur].ctx, &g_sched); 
 inline void barrier() {
     g_fibers[g_cur].st = AT_BARRIER;
     yield_to_scheduler();
+}
+
+// EMU_PREEMPT=<seed>: every atomic operation is a possible switch to another thread (one time in four), so that
+// what other threads do falls between a thread's atomics and the plain accesses around them, not only
+// between its synchronisation points.
+inline void preempt_point() {
+    static const char* e = getenv("EMU_PREEMPT");
+    static u64 rng = e ? strtoull(e, nullptr, 0) * 0x9E3779B97F4A7C15ull + 12345 : 0;
+    if (!e || g_cur < 0) {
+        return;
+    }
+    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+    if (((rng >> 40) & 3) == 0) {
+        g_fibers[g_cur].st = READY;
+        yield_to_scheduler();
+    }
 }
 
 // Publishes v; returns the values and the set of the lanes of this wave that took part.
@@ -813,48 +830,56 @@ static inline unsigned max(unsigned a, int b) { return max(a, (unsigned)b); }
 
 template <typename T>
 static inline T atomicAdd(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = o + v;
     return o;
 }
 template <typename T>
 static inline T atomicSub(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = o - v;
     return o;
 }
 template <typename T>
 static inline T atomicMin(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = v < o ? v : o;
     return o;
 }
 template <typename T>
 static inline T atomicMax(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = o < v ? v : o;
     return o;
 }
 template <typename T>
 static inline T atomicOr(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = o | v;
     return o;
 }
 template <typename T>
 static inline T atomicAnd(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = o & v;
     return o;
 }
 template <typename T>
 static inline T atomicExch(T* p, T v) {
+    emu::preempt_point();
     const T o = *p;
     *p = v;
     return o;
 }
 template <typename T>
 static inline T atomicCAS(T* p, T expected, T v) {
+    emu::preempt_point();
     const T o = *p;
     if (o == expected) {
         *p = v;
