@@ -69,3 +69,16 @@ def test_hamming_database_triangulation_area_and_landmark_kernels():
     k = run("others", {"EMU_REVERSE": "1"})
     for name in ("k_hamming_pairs", "k_hamming_matrix", "k_knn2_partial", "k_window_list", "k_landmark_median", "k_proj_resolve"):
         assert k[name] > 0, name
+
+
+def test_hostile_inputs_touch_no_foreign_memory():
+    """tools/emu/fuzz_entry_points.py: keypoints and reprojections outside the image, NaN / infinite coordinates,
+    octaves outside the pyramid, index lists past their arrays, damaged vocabularies, counts outside [0, capacity] --
+    a dozen seeds per entry-point family on the host build, where a touch of memory that is not the library's own
+    ends the process (on the device: a GPU memory fault).  Return codes are not judged."""
+    fuzz = os.path.join(ROOT, "tools", "emu", "fuzz_entry_points.py")
+    e = dict(os.environ)
+    for k in ("OVS_RESOLVE", "OVS_GROUP_LIVE", "EMU_SHUFFLE", "EMU_REVERSE", "EMU_STRICT_LDS", "EMU_PREEMPT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, fuzz, "--seeds", "0:12"], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-1500:] + r.stderr[-4000:]

@@ -305,10 +305,19 @@ def fuzz_extract(rng):
         L.ovs_orb_set_blur_kernel(hnd, 1)
     rc = L.ovs_orb_extract(hnd, A.ptr(img, A.u8p), w, h, img.strides[0], A.ptr(mask, A.u8p), w if mask is not None else 0, A.ptr(kp, A.kpp), A.ptr(desc, A.u8p),
                            cap, C.byref(n))
-    if rc == 0 and rng.random() < 0.5:
-        # a second frame on the same handle, smaller or larger
+    for _ in range(int(rng.integers(0, 3))):
+        # more frames on the same handle: the same size, or another one (the plan and the buffers are rebuilt)
+        if rc != 0:
+            break
+        if rng.random() < 0.6:
+            w, h = int(rng.choice([64, 100, 253, 320, 400, 640])), int(rng.choice([64, 100, 240, 300, 480]))
+        cap2 = L.ovs_orb_keypoint_capacity(hnd, w, h)
+        if cap2 <= 0:
+            break
+        kp2 = np.zeros(cap2, dtype=A.KEYPOINT_DTYPE)
+        desc2 = np.zeros((cap2, 32), np.uint8)
         img2 = rng.integers(0, 256, (h, w), dtype=np.uint8)
-        rc = L.ovs_orb_extract(hnd, A.ptr(img2, A.u8p), w, h, img2.strides[0], A.ptr(None, A.u8p), 0, A.ptr(kp, A.kpp), A.ptr(desc, A.u8p), cap, C.byref(n))
+        rc = L.ovs_orb_extract(hnd, A.ptr(img2, A.u8p), w, h, img2.strides[0], A.ptr(None, A.u8p), 0, A.ptr(kp2, A.kpp), A.ptr(desc2, A.u8p), cap2, C.byref(n))
     L.ovs_orb_destroy(hnd)
     return rc
 
