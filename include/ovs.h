@@ -468,7 +468,7 @@ typedef struct ovs_bow_vocab_view {
     const uint8_t* node_descs;     /* num_nodes x 32 bytes (row 0, the root's, is not read) */
     const uint32_t* child_offsets; /* num_nodes + 1, ascending */
     const uint32_t* children;      /* child_offsets[num_nodes] node ids */
-    const uint32_t* word_ids;      /* num_nodes, read for leaves */
+    const uint32_t* word_ids;      /* num_nodes, read for leaves; any value but 0xFFFFFFFF */
     const double* weights;         /* num_nodes, read for leaves */
 } ovs_bow_vocab_view;
 

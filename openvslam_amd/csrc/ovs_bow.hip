@@ -36,7 +36,9 @@ struct ovs_bow_vocab {
 
 namespace {
 
-constexpr u64 kStopped = ~0ull; // sort key of a descriptor whose word has weight <= 0
+// sort key of a descriptor whose word has weight <= 0: behind every node id (< 2^31) and every word id (the
+// vocabulary is refused when a word id is 0xFFFFFFFF)
+constexpr u32 kStopped = 0xFFFFFFFFu;
 constexpr u32 kChildPosBits = 22;
 
 struct bow_tree_dev {
@@ -60,7 +62,7 @@ __device__ __forceinline__ u32 row_min_u32(u32 v) {
 
 __global__ __launch_bounds__(256) void k_bow_descend(bow_tree_dev t, const uint8_t* __restrict__ descs, const int* __restrict__ counts, int fixed_n,
                                                      int cap, u32* __restrict__ word_of, u32* __restrict__ node_of, double* __restrict__ weight_of,
-                                                     u64* __restrict__ key_node, u64* __restrict__ key_word) {
+                                                     u32* __restrict__ key_node, u32* __restrict__ key_word) {
     const int frame = blockIdx.y;
     const int n = min(counts ? counts[frame] : fixed_n, cap);
     const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -111,52 +113,83 @@ __global__ __launch_bounds__(256) void k_bow_descend(bow_tree_dev t, const uint8
             node_of[o] = nid;
         }
         weight_of[o] = w;
-        key_node[o] = stopped ? kStopped : (u64)nid;
-        key_word[o] = stopped ? kStopped : (u64)word;
+        key_node[o] = stopped ? kStopped : (u32)nid;
+        key_word[o] = stopped ? kStopped : (u32)word;
     }
 }
 
 // rank of descriptor i among the keys of its frame in (key, index) order: the position std::map iteration
-// followed by the per-key vectors (indices pushed in ascending order) gives it
-__global__ __launch_bounds__(256) void k_bow_rank(const int* __restrict__ counts, int fixed_n, int cap, const u64* __restrict__ key_node,
-                                                  const u64* __restrict__ key_word, const double* __restrict__ weight_of,
+// followed by the per-key vectors (indices pushed in ascending order) gives it.  A workgroup ranks 64
+// descriptors (one per lane); the keys of the frame pass through LDS in tiles of 256, and each of the four
+// waves compares its lanes' keys with a quarter of every tile (all lanes of a wave read the same LDS word: a
+// broadcast), so a frame of 2000 descriptors is 32 workgroups of 500 steps instead of 8 of 2000.  Only the
+// tile that holds the workgroup's own descriptors needs the index comparison; in the tiles before it an
+// equal key counts, in the tiles behind it it does not.
+constexpr int kRankLanes = 64, kRankTile = 256;
+__global__ __launch_bounds__(256) void k_bow_rank(const int* __restrict__ counts, int fixed_n, int cap, const u32* __restrict__ key_node,
+                                                  const u32* __restrict__ key_word, const double* __restrict__ weight_of,
                                                   u32* __restrict__ sorted_node, u32* __restrict__ sorted_node_idx, u32* __restrict__ sorted_word,
                                                   double* __restrict__ sorted_word_weight) {
-    __shared__ u64 s_kn[256];
-    __shared__ u64 s_kw[256];
+    __shared__ uint2 s_keys[kRankTile]; // x: node key, y: word key
+    __shared__ u32 s_part[2][4][kRankLanes];
     const int frame = blockIdx.y;
     const int n = min(counts ? counts[frame] : fixed_n, cap);
-    if ((int)blockIdx.x * 256 >= n) {
+    const int i0 = (int)blockIdx.x * kRankLanes;
+    if (i0 >= n) {
         return;
     }
     const size_t fo = (size_t)frame * cap;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const u64 kn = i < n ? key_node[fo + i] : kStopped;
-    const u64 kw = i < n ? key_word[fo + i] : kStopped;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = i0 + lane;
+    const u32 kn = i < n ? key_node[fo + i] : kStopped;
+    const u32 kw = i < n ? key_word[fo + i] : kStopped;
     u32 rn = 0, rw = 0;
-    for (int j0 = 0; j0 < n; j0 += 256) {
-        const int j = j0 + (int)threadIdx.x;
+    for (int j0 = 0; j0 < n; j0 += kRankTile) {
+        const int j = j0 + tid;
         __syncthreads();
-        s_kn[threadIdx.x] = j < n ? key_node[fo + j] : kStopped;
-        s_kw[threadIdx.x] = j < n ? key_word[fo + j] : kStopped;
+        s_keys[tid] = make_uint2(j < n ? key_node[fo + j] : kStopped, j < n ? key_word[fo + j] : kStopped);
         __syncthreads();
-        const int m = min(256, n - j0);
-        for (int k = 0; k < m; ++k) {
-            const u64 a = s_kn[k], b = s_kw[k];
-            const bool before = j0 + k < i;
-            rn += (a < kn) || (a == kn && before);
-            rw += (b < kw) || (b == kw && before);
+        const int m = min(kRankTile, n - j0);
+        const int kb = wave * (kRankTile / 4), ke = min(kb + kRankTile / 4, m);
+        if (j0 + kRankTile <= i0) {
+            // every key of the tile has a smaller index than the workgroup's descriptors
+            for (int k = kb; k < ke; ++k) {
+                const uint2 o = s_keys[k];
+                rn += o.x <= kn;
+                rw += o.y <= kw;
+            }
+        }
+        else if (i0 + kRankLanes <= j0) {
+            for (int k = kb; k < ke; ++k) {
+                const uint2 o = s_keys[k];
+                rn += o.x < kn;
+                rw += o.y < kw;
+            }
+        }
+        else {
+            for (int k = kb; k < ke; ++k) {
+                const uint2 o = s_keys[k];
+                const bool before = j0 + k < i;
+                rn += (o.x < kn) || (o.x == kn && before);
+                rw += (o.y < kw) || (o.y == kw && before);
+            }
         }
     }
-    if (i < n) {
-        sorted_node[fo + rn] = (u32)kn;
+    s_part[0][wave][lane] = rn;
+    s_part[1][wave][lane] = rw;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+        rn = s_part[0][0][lane] + s_part[0][1][lane] + s_part[0][2][lane] + s_part[0][3][lane];
+        rw = s_part[1][0][lane] + s_part[1][1][lane] + s_part[1][2][lane] + s_part[1][3][lane];
+        sorted_node[fo + rn] = kn;
         sorted_node_idx[fo + rn] = (u32)i;
-        sorted_word[fo + rw] = (u32)kw;
+        sorted_word[fo + rw] = kw;
         sorted_word_weight[fo + rw] = weight_of[fo + i];
     }
 }
 
 constexpr int kCompactThreads = 1024;
+constexpr int kNormChunk = 4096; // terms of the norm staged in LDS at a time (32 KB)
 
 // inclusive scan over the workgroup; `red` holds one word per wave plus the total
 __device__ __forceinline__ u32 block_incl_scan_u32(u32 x, u32* red, u32& total) {
@@ -178,7 +211,7 @@ __device__ __forceinline__ u32 block_incl_scan_u32(u32 x, u32* red, u32& total) 
 }
 
 __global__ __launch_bounds__(kCompactThreads) void k_bow_compact(const int* __restrict__ counts, int fixed_n, int cap, int weighting, int scoring,
-                                                                 const u64* __restrict__ key_node, const u32* __restrict__ sorted_node,
+                                                                 const u32* __restrict__ key_node, const u32* __restrict__ sorted_node,
                                                                  const u32* __restrict__ sorted_node_idx, const u32* __restrict__ sorted_word,
                                                                  const double* __restrict__ sorted_word_weight, u32* __restrict__ word_start,
                                                                  u32* __restrict__ bow_word_ids, double* __restrict__ bow_values, int* __restrict__ num_words_out,
@@ -186,6 +219,7 @@ __global__ __launch_bounds__(kCompactThreads) void k_bow_compact(const int* __re
                                                                  int* __restrict__ fv_num_nodes_out) {
     __shared__ u32 red[kCompactThreads / 64];
     __shared__ double s_norm;
+    __shared__ double s_terms[kNormChunk];
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int n = min(counts ? counts[frame] : fixed_n, cap);
     const size_t fo = (size_t)frame * cap;
@@ -268,17 +302,41 @@ __global__ __launch_bounds__(kCompactThreads) void k_bow_compact(const int* __re
     }
     __syncthreads();
     if (must) {
-        // BowVector::normalize: the norm is accumulated in map order
-        if (tid == 0) {
-            double norm = 0.0;
-            for (u32 s = 0; s < num_words; ++s) {
-                const double v = bow_values[s];
-                norm = __dadd_rn(norm, l2 ? __dmul_rn(v, v) : fabs(v));
+        // BowVector::normalize: the norm is accumulated in map order, a chain of dependent double additions that
+        // one lane walks.  The terms come to it through LDS, a chunk at a time (everybody loads, one lane adds:
+        // read from global memory one by one, the 2000 values of a frame cost 0.1 ms of load latency).
+        double norm = 0.0;
+        for (u32 c0 = 0; c0 < num_words; c0 += kNormChunk) {
+            const u32 m = min((u32)kNormChunk, num_words - c0);
+            __syncthreads(); // the previous chunk has been added
+            for (u32 s = tid; s < m; s += kCompactThreads) {
+                const double v = bow_values[c0 + s];
+                s_terms[s] = l2 ? __dmul_rn(v, v) : fabs(v);
             }
+            __syncthreads();
+            if (tid == 0) {
+                u32 s = 0;
+                for (; s + 8 <= m; s += 8) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        t[u] = s_terms[s + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        norm = __dadd_rn(norm, t[u]);
+                    }
+                }
+                for (; s < m; ++s) {
+                    norm = __dadd_rn(norm, s_terms[s]);
+                }
+            }
+        }
+        if (tid == 0) {
             s_norm = l2 ? __dsqrt_rn(norm) : norm;
         }
         __syncthreads();
-        const double norm = s_norm;
+        norm = s_norm;
         if (norm > 0.0) {
             for (u32 s = tid; s < num_words; s += kCompactThreads) {
                 bow_values[s] = __ddiv_rn(bow_values[s], norm);
@@ -297,8 +355,8 @@ int check_vocab(const ovs_bow_vocab* v) {
 // scratch per descriptor slot of a batch, carved from an arena
 struct bow_scratch {
     double* weight_of;
-    u64* key_node;
-    u64* key_word;
+    u32* key_node;
+    u32* key_word;
     u32* sorted_node;
     u32* sorted_node_idx;
     u32* sorted_word;
@@ -306,13 +364,13 @@ struct bow_scratch {
     u32* word_start;
     static size_t bytes(size_t frames, size_t cap) {
         const size_t fc = frames * cap;
-        return 3 * al(fc * 8) + 3 * al(fc * 4) + al(fc * 8) + al(frames * (cap + 1) * 4);
+        return al(fc * 8) + 5 * al(fc * 4) + al(fc * 8) + al(frames * (cap + 1) * 4);
     }
     void carve(carver& cv, size_t frames, size_t cap) {
         const size_t fc = frames * cap;
         weight_of = cv.take<double>(fc);
-        key_node = cv.take<u64>(fc);
-        key_word = cv.take<u64>(fc);
+        key_node = cv.take<u32>(fc);
+        key_word = cv.take<u32>(fc);
         sorted_node = cv.take<u32>(fc);
         sorted_node_idx = cv.take<u32>(fc);
         sorted_word = cv.take<u32>(fc);
@@ -334,7 +392,7 @@ int launch_transform(const ovs_bow_vocab* v, const uint8_t* d_descs, const int32
     t.max_depth = v->max_depth;
     OVS_LAUNCH("k_bow_descend", k_bow_descend, dim3((cap + 15) / 16, n_frames), dim3(256), 0, st, t, d_descs, d_counts, fixed_n, cap, d_word_of, d_node_of,
                s.weight_of, s.key_node, s.key_word);
-    OVS_LAUNCH("k_bow_rank", k_bow_rank, dim3((cap + 255) / 256, n_frames), dim3(256), 0, st, d_counts, fixed_n, cap, s.key_node, s.key_word, s.weight_of,
+    OVS_LAUNCH("k_bow_rank", k_bow_rank, dim3((cap + kRankLanes - 1) / kRankLanes, n_frames), dim3(256), 0, st, d_counts, fixed_n, cap, s.key_node, s.key_word, s.weight_of,
                s.sorted_node, s.sorted_node_idx, s.sorted_word, s.sorted_word_weight);
     OVS_LAUNCH("k_bow_compact", k_bow_compact, dim3(n_frames), dim3(kCompactThreads), 0, st, d_counts, fixed_n, cap, v->weighting, v->scoring, s.key_node,
                s.sorted_node, s.sorted_node_idx, s.sorted_word, s.sorted_word_weight, s.word_start, d_bow_word_ids, d_bow_values, d_num_words,
@@ -366,6 +424,11 @@ int ovs_bow_vocab_create(const ovs_bow_vocab_view* view, int device, ovs_bow_voc
     for (long long i = 0; i < nn; ++i) {
         if (co[i + 1] < co[i] || co[i + 1] - co[i] >= (1u << kChildPosBits)) {
             return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "vocabulary view: child_offsets not ascending (or 2^22 children of one node)");
+        }
+    }
+    for (long long i = 0; i < nn && nn > 1; ++i) {
+        if (view->word_ids[i] == 0xFFFFFFFFu) {
+            return ovs::fail(OVS_ERR_INVALID_ARGUMENT, "vocabulary view: word id 0xFFFFFFFF is not supported");
         }
     }
     std::vector<uint8_t> seen(nn, 0);
