@@ -174,9 +174,16 @@ inline bool guarded_free(void* p) {
     if (it == blocks().end() || !it->second.live) {
         return false;
     }
-    // the range stays reserved and inaccessible: a use after free faults
-    mprotect(it->second.map, it->second.map_bytes, PROT_NONE);
-    madvise(it->second.map, it->second.map_bytes, MADV_DONTNEED);
+    // the block and 64 MiB on either side stay reserved and inaccessible: a use after free faults; the rest of the
+    // range behind it goes back (a long run would otherwise use up the address space)
+    const size_t body = (std::max<size_t>(it->second.bytes, 1) + 4095) / 4096 * 4096;
+    const size_t keep = std::min<size_t>(it->second.map_bytes, ((size_t)64 << 20) + body + ((size_t)64 << 20)); // the guard in front is 64 MiB
+    mprotect(it->second.map, keep, PROT_NONE);
+    madvise(it->second.map, keep, MADV_DONTNEED);
+    if (keep < it->second.map_bytes) {
+        munmap(it->second.map + keep, it->second.map_bytes - keep);
+        it->second.map_bytes = keep;
+    }
     it->second.live = false;
     return true;
 }
