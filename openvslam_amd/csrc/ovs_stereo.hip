@@ -40,11 +40,14 @@ struct stereo_images {
     long long kp_stride, rows_stride, items_stride;
 };
 
-__global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restrict__ kr, const int* __restrict__ n_ptr, int n_fixed,
+// T threads per pair: 256 in batches (many pairs fill the device), 1024 for a call with a few pairs, where the chains of
+// dependent LDS reads of one workgroup (entry -> row -> row bounds -> the row's entries) are what the caller waits for.
+template <int T>
+__global__ __launch_bounds__(T) void k_stereo_rows(const ovs_keypoint* __restrict__ kr, const int* __restrict__ n_ptr, int n_fixed,
                                                      stereo_images im, u32* __restrict__ row_start, u32* __restrict__ row_items, int items_cap,
                                                      int lds_items, int* __restrict__ err) {
     extern __shared__ u32 sm[];
-    __shared__ u32 red[8];
+    __shared__ u32 red[T / 64];
     const int pair = blockIdx.y;
     const int n = n_ptr ? min(max(n_ptr[pair], 0), n_fixed) : n_fixed;
     const int rows = im.lh[0];
@@ -54,11 +57,11 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
     u32* cnt = sm;            // rows + 1
     u32* cur = sm + rows + 1; // rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i <= rows; i += 256) {
+    for (int i = tid; i <= rows; i += T) {
         cnt[i] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += T) {
         const ovs_keypoint kp = kr[i];
         if (kp.octave < 0 || im.num_levels <= kp.octave) {
             *err = OVS_ERR_OUT_OF_RANGE;
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
     }
     __syncthreads();
     {
-        const int per = (rows + 1 + 255) / 256;
+        const int per = (rows + 1 + T - 1) / T;
         const int b = min(tid * per, rows + 1), e = min(b + per, rows + 1);
         u32 sum = 0;
         for (int i = b; i < e; ++i) {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
     }
     __syncthreads();
     const bool fits = cnt[rows] <= (u32)items_cap;
-    for (int i = tid; i <= rows; i += 256) {
+    for (int i = tid; i <= rows; i += T) {
         row_start[i] = fits ? cnt[i] : 0u;
         if (i < rows) {
             cur[i] = cnt[i];
@@ -114,10 +117,10 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
     }
     __syncthreads();
     // scatter the keypoint indices into their rows, then order every row's list (the reference
-    // appends in keypoint order); done in LDS when the pair's lists fit behind the row tables
-    // (`lds_items` words), the per-row insertion sorts being chains of dependent accesses
+    // appends in keypoint order).  In global memory (lists that do not fit in LDS behind the row tables,
+    // `lds_items` words): one insertion sort per row.
     auto fill_and_sort = [&](u32* items) {
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += T) {
             const ovs_keypoint kp = kr[i];
             if (kp.octave < 0 || im.num_levels <= kp.octave) {
                 continue;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
             }
         }
         __syncthreads();
-        for (int row = tid; row < rows; row += 256) {
+        for (int row = tid; row < rows; row += T) {
             const u32 b = cnt[row], e = cnt[row + 1];
             for (u32 i = b + 1; i < e; ++i) {
                 const u32 v = items[i];
@@ -144,12 +147,36 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const ovs_keypoint* __restr
         }
     };
     const u32 total_items = cnt[rows];
-    if (total_items <= (u32)lds_items) {
+    constexpr int kIdxBits = 19;
+    if (total_items <= (u32)lds_items && n < (1 << kIdxBits)) {
+        // The lists in LDS, unordered, every entry tagged with its row (row << 19 | keypoint index: rows are below
+        // 8191).  An entry's place in its row is the number of entries of that row with a smaller keypoint index:
+        // one thread per entry counts them and writes the index straight to its final place in global memory.
+        // All reads are independent of each other (the insertion sorts of the rows were chains of dependent LDS
+        // accesses: 47 of the kernel's 60 us for 1000 keypoints).
         u32* litems = sm + 2 * rows + 1;
-        fill_and_sort(litems);
+        for (int i = tid; i < n; i += T) {
+            const ovs_keypoint kp = kr[i];
+            if (kp.octave < 0 || im.num_levels <= kp.octave) {
+                continue;
+            }
+            const float r = __fmul_rn(2.0f, im.scale[kp.octave]);
+            const int max_r = cv_ceil_ff(__fadd_rn(kp.y, r));
+            const int min_r = cv_floor_ff(__fsub_rn(kp.y, r));
+            for (int row = max(min_r, 0); row <= min(max_r, rows - 1); ++row) {
+                litems[atomicAdd(&cur[row], 1u)] = ((u32)row << kIdxBits) | (u32)i;
+            }
+        }
         __syncthreads();
-        for (u32 i = tid; i < total_items; i += 256) {
-            row_items[i] = litems[i];
+        for (u32 p = tid; p < total_items; p += T) {
+            const u32 w = litems[p];
+            const u32 row = w >> kIdxBits;
+            const u32 b = cnt[row], e = cnt[row + 1];
+            u32 rank = 0;
+            for (u32 q = b; q < e; ++q) {
+                rank += litems[q] < w;
+            }
+            row_items[b + rank] = w & ((1u << kIdxBits) - 1u);
         }
     }
     else {
@@ -423,7 +450,12 @@ int launch_stereo(const stereo_images& im, const ovs_keypoint* d_kl, const uint8
     const int lds_items = lds_tables < 60 * 1024 ? static_cast<int>(std::min<size_t>((60 * 1024 - lds_tables) / sizeof(u32), static_cast<size_t>(std::max(items_cap, 0)))) : 0;
     const size_t lds = lds_tables + static_cast<size_t>(lds_items) * sizeof(u32);
     const float max_disp = focal_x_baseline / true_baseline; // stereo.cc:16
-    OVS_LAUNCH("k_stereo_rows", k_stereo_rows, dim3(1, n_pairs), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, lds_items, d_err);
+    if (n_pairs <= 8) {
+        OVS_LAUNCH("k_stereo_rows", k_stereo_rows<1024>, dim3(1, n_pairs), dim3(1024), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, lds_items, d_err);
+    }
+    else {
+        OVS_LAUNCH("k_stereo_rows", k_stereo_rows<256>, dim3(1, n_pairs), dim3(256), lds, st, d_kr, d_nr, nr, im, d_row_start, d_row_items, items_cap, lds_items, d_err);
+    }
     if (cap_l > 0) {
         OVS_LAUNCH("k_stereo_match", k_stereo_match, dim3((cap_l + 256 / kSG - 1) / (256 / kSG), n_pairs), dim3(256), 0, st,
                    d_kl, d_dl, d_nl, nl, d_kr, d_dr, im, d_row_start, d_row_items, focal_x_baseline, max_disp, d_x_right, d_depth, d_corr, d_err);
