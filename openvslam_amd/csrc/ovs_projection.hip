@@ -33,7 +33,7 @@ using namespace ovsm;
 namespace {
 
 constexpr int kTopK = 8;
-constexpr int kGroupLive = 16; // lanes per query when a call has a few problems (OVS_GROUP_LIVE=8 keeps kGroup)
+constexpr int kGroupLive = 64; // lanes per query when a call has a few problems: a wave per query (16 lanes: 16.2 us for the 2241 queries of a frame, 64: 10.5; OVS_GROUP_LIVE=8 keeps kGroup)
 constexpr int kGroup = 8; // lanes per query in k_proj_candidates (16: 0.29 ms, 8: 0.21 ms, 4: 0.46 ms per 255 x 2243 queries)
 
 enum proj_kind {
